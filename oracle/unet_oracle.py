@@ -1,0 +1,389 @@
+"""CPU oracle for the FloodPlanet UNet training step.  TEST INFRASTRUCTURE ONLY.
+
+This file is a restatement, in functional torch-CPU fp32, of the arithmetic the
+reference executes on its hot path.  It is the *checker* for the HIP path: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it.  Nothing under ``floodplanet_code_amd/`` imports it and the
+product path never falls back to it.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` (run in the development
+container, where ``/root/reference`` is mounted) imports the reference's own
+``st_water_seg/models/unet.py`` by file path, loads the same parameters into it
+and into this restatement, and checks logits / loss / every gradient / BN
+buffers / Adam-updated parameters for bit equality before writing the fixtures
+under ``tests/golden/``.  ``tests/test_oracle_golden.py`` re-checks this file
+against those fixtures on every run (CPU).
+
+What is restated (reference file:line, relative to /root/reference):
+  * DoubleConv         st_water_seg/models/unet.py:6-20
+  * Down               st_water_seg/models/unet.py:23-32
+  * Up (both variants) st_water_seg/models/unet.py:35-67
+  * OutConv            st_water_seg/models/unet.py:70-77
+  * UNet wiring        st_water_seg/models/unet.py:80-111 (and the
+                       base_feat_channels generalisation of :134-200)
+  * forward of the plugin + early-fusion concat
+                       st_water_seg/models/water_seg_model.py:87-90,
+                       st_water_seg/models/ef_model.py:24-47
+  * training_step loss st_water_seg/models/water_seg_model.py:98-108
+                       (CrossEntropyLoss(ignore_index) :40, NaN guard :104-106,
+                       argmax :107)
+  * optimiser          st_water_seg/models/water_seg_model.py:198-205
+                       (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8,
+                       no weight decay, bias correction)
+  * metric counters    st_water_seg/models/water_seg_model.py:46-63 (micro
+                       F1 / Jaccard / Accuracy with ignore_index; torchmetrics
+                       itself is third-party and absent, so these three are
+                       "parity unpinned" -- see metrics_from_counts()).
+
+Parameters live in a flat ``dict`` whose keys and shapes are exactly the
+reference ``UNet.state_dict()`` keys (OIHW fp32), so a state dict moves between
+the reference, this oracle and the HIP module unchanged.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5          # nn.BatchNorm2d default (unet.py:15,17)
+BN_MOMENTUM = 0.1      # nn.BatchNorm2d default
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
+EF_EXTRA_KEYS = ("dem", "slope", "preflood", "pre_post_difference", "hand")  # ef_model.py:28-41
+
+
+# --------------------------------------------------------------------------- #
+# architecture description
+# --------------------------------------------------------------------------- #
+def channel_plan(n_channels: int, base: int = 64, bilinear: bool = True):
+    """Channel plan of unet.py:88-98 / :143-149 / :176-183 (channel_factor=1).
+
+    Returns (enc, dec) where enc[i] = (prefix, cin, cmid, cout) for inc/down1..4 and
+    dec[i] = (prefix, c_low, c_skip, cmid, cout) for up1..4.
+    """
+    factor = 2 if bilinear else 1
+    e = [base, base * 2, base * 4, base * 8, (base * 16) // factor]
+    enc = [("inc.double_conv", n_channels, e[0], e[0])]
+    for i in range(1, 5):
+        enc.append((f"down{i}.maxpool_conv.1.double_conv", e[i - 1], e[i], e[i]))
+    dec = []
+    low = e[4]
+    outs = [(base * 8) // factor, (base * 4) // factor, (base * 2) // factor, base]
+    for k in range(4):
+        skip = e[3 - k]
+        if bilinear:
+            cin = low + skip
+            mid = cin // 2
+        else:
+            # ConvTranspose2d(in, in//2) where in = 2*skip
+            cin = (low // 2) + skip
+            mid = outs[k]
+        dec.append((f"up{k + 1}", low, skip, mid, outs[k]))
+        low = outs[k]
+    return enc, dec
+
+
+def param_spec(n_channels: int, n_classes: int, base: int = 64,
+               bilinear: bool = True) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """state_dict key -> (shape, kind) in the reference's registration order.
+
+    kind in {conv_w, conv_b, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, convT_w, convT_b}.
+    """
+    enc, dec = channel_plan(n_channels, base, bilinear)
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+
+    def double_conv(prefix, cin, cmid, cout):
+        for idx, (ci, co) in ((0, (cin, cmid)), (3, (cmid, cout))):
+            spec[f"{prefix}.{idx}.weight"] = ((co, ci, 3, 3), "conv_w")
+            spec[f"{prefix}.{idx}.bias"] = ((co,), "conv_b")
+            b = idx + 1
+            spec[f"{prefix}.{b}.weight"] = ((co,), "bn_w")
+            spec[f"{prefix}.{b}.bias"] = ((co,), "bn_b")
+            spec[f"{prefix}.{b}.running_mean"] = ((co,), "bn_rm")
+            spec[f"{prefix}.{b}.running_var"] = ((co,), "bn_rv")
+            spec[f"{prefix}.{b}.num_batches_tracked"] = ((), "bn_nbt")
+
+    for prefix, cin, cmid, cout in enc:
+        double_conv(prefix, cin, cmid, cout)
+    for prefix, low, skip, mid, cout in dec:
+        if bilinear:
+            double_conv(f"{prefix}.conv.double_conv", low + skip, mid, cout)
+        else:
+            spec[f"{prefix}.up.weight"] = ((low, low // 2, 2, 2), "convT_w")
+            spec[f"{prefix}.up.bias"] = ((low // 2,), "convT_b")
+            double_conv(f"{prefix}.conv.double_conv", low // 2 + skip, mid, cout)
+    spec["outc.conv.weight"] = ((n_classes, base, 1, 1), "conv_w")
+    spec["outc.conv.bias"] = ((n_classes,), "conv_b")
+    return spec
+
+
+def is_trainable(kind: str) -> bool:
+    return kind in ("conv_w", "conv_b", "bn_w", "bn_b", "convT_w", "convT_b")
+
+
+# --------------------------------------------------------------------------- #
+# deterministic, framework-independent generator (fixtures never ship weights)
+# --------------------------------------------------------------------------- #
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(n: int, seed: int, stream: int) -> np.ndarray:
+    """n float64 values in [0,1): u[i] = splitmix64(i + 2^32*stream + 2^48*seed) >> 11 / 2^53."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        key = idx + (np.uint64(stream) << np.uint64(32)) + (np.uint64(seed) << np.uint64(48))
+        z = _splitmix64(key)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def make_state(n_channels: int, n_classes: int, base: int = 64, bilinear: bool = True,
+               seed: int = 0, nontrivial_bn: bool = True) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic parameters.  conv: U(+-1/sqrt(fan_in)) like torch's default init
+    (kaiming_uniform(a=sqrt(5))), BN gamma U(0.5,1.5) / beta U(-0.2,0.2) when
+    nontrivial_bn (so affine paths are exercised), else ones/zeros."""
+    st: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for stream, (name, (shape, kind)) in enumerate(param_spec(n_channels, n_classes, base, bilinear).items()):
+        n = int(np.prod(shape)) if len(shape) else 1
+        if kind in ("conv_w", "convT_w"):
+            fan_in = shape[1] * shape[2] * shape[3] if kind == "conv_w" else shape[1] * shape[2] * shape[3]
+            bound = 1.0 / math.sqrt(fan_in)
+            v = (hash_uniform(n, seed, stream) * 2.0 - 1.0) * bound
+        elif kind in ("conv_b", "convT_b"):
+            v = (hash_uniform(n, seed, stream) * 2.0 - 1.0) * 0.1
+        elif kind == "bn_w":
+            v = 0.5 + hash_uniform(n, seed, stream) if nontrivial_bn else np.ones(n)
+        elif kind == "bn_b":
+            v = (hash_uniform(n, seed, stream) - 0.5) * 0.4 if nontrivial_bn else np.zeros(n)
+        elif kind == "bn_rm":
+            v = np.zeros(n)
+        elif kind == "bn_rv":
+            v = np.ones(n)
+        elif kind == "bn_nbt":
+            st[name] = torch.zeros((), dtype=torch.int64)
+            continue
+        else:
+            raise AssertionError(kind)
+        st[name] = torch.from_numpy(v.astype(np.float32)).reshape(shape).clone()
+    return st
+
+
+def make_batch(B: int, C: int, H: int, W: int, seed: int = 1, n_label_values: int = 2,
+               all_ignored_sample: Optional[int] = None, ignore_value: int = 0,
+               extra: Tuple[str, ...] = ()) -> Dict[str, torch.Tensor]:
+    """Synthetic tile batch shaped like Floodplanet_Dataset.__getitem__ output
+    (floodplanet.py:644-648): image f32 [B,C,H,W] in [0,1), target i64 [B,H,W] made of
+    smooth blobs over {0..n_label_values-1}."""
+    img = hash_uniform(B * C * H * W, seed, 1).astype(np.float32).reshape(B, C, H, W)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    tgt = np.zeros((B, H, W), dtype=np.int64)
+    ph = hash_uniform(B * 6, seed, 2).reshape(B, 6)
+    for b in range(B):
+        f = (np.sin(yy * (0.11 + 0.2 * ph[b, 0]) + 6.28 * ph[b, 1])
+             + np.cos(xx * (0.09 + 0.2 * ph[b, 2]) + 6.28 * ph[b, 3])
+             + np.sin((xx + yy) * (0.05 + 0.1 * ph[b, 4]) + 6.28 * ph[b, 5]))
+        q = (f - f.min()) / (f.max() - f.min() + 1e-9)
+        tgt[b] = np.minimum((q * n_label_values).astype(np.int64), n_label_values - 1)
+    if all_ignored_sample is not None:
+        tgt[all_ignored_sample] = ignore_value
+    batch = {"image": torch.from_numpy(img), "target": torch.from_numpy(tgt)}
+    for j, key in enumerate(extra):
+        e = hash_uniform(B * H * W, seed, 10 + j).astype(np.float32).reshape(B, 1, H, W)
+        batch[key] = torch.from_numpy(e)
+    return batch
+
+
+# --------------------------------------------------------------------------- #
+# forward
+# --------------------------------------------------------------------------- #
+def _conv_bn_relu(x, st, prefix, idx, training):
+    w, b = st[f"{prefix}.{idx}.weight"], st[f"{prefix}.{idx}.bias"]
+    y = F.conv2d(x, w, b, stride=1, padding=1)                      # unet.py:14,16
+    bn = f"{prefix}.{idx + 1}"
+    if training:
+        # nn.BatchNorm2d.forward: bump the counter, then batch statistics
+        st[f"{bn}.num_batches_tracked"] += 1
+    y = F.batch_norm(y, st[f"{bn}.running_mean"], st[f"{bn}.running_var"],
+                     st[f"{bn}.weight"], st[f"{bn}.bias"], training, BN_MOMENTUM, BN_EPS)
+    return F.relu(y)                                                # unet.py:15,17
+
+
+def _double_conv(x, st, prefix, training):
+    x = _conv_bn_relu(x, st, prefix, 0, training)
+    return _conv_bn_relu(x, st, prefix, 3, training)
+
+
+def assemble_input(batch: Dict[str, torch.Tensor], early_fusion: bool) -> torch.Tensor:
+    """water_seg_model.py:87-90 (image only) or ef_model.py:24-47 (concat extras in fixed order)."""
+    x = batch["image"]
+    if early_fusion:
+        for key in EF_EXTRA_KEYS:
+            if key in batch:
+                x = torch.concat([x, batch[key]], dim=1)
+    return x
+
+
+def unet_forward(st: Dict[str, torch.Tensor], x: torch.Tensor, training: bool,
+                 bilinear: bool = True) -> torch.Tensor:
+    """unet.py:100-111.  Mutates BN running buffers in `st` when training (as nn.BatchNorm2d does)."""
+    feats = [_double_conv(x, st, "inc.double_conv", training)]
+    for i in range(1, 5):
+        p = F.max_pool2d(feats[-1], 2)                              # unet.py:29
+        feats.append(_double_conv(p, st, f"down{i}.maxpool_conv.1.double_conv", training))
+    cur = feats[4]
+    for k in range(4):
+        skip = feats[3 - k]
+        if bilinear:
+            up = F.interpolate(cur, scale_factor=2, mode="bilinear", align_corners=True)  # unet.py:43-45
+        else:
+            up = F.conv_transpose2d(cur, st[f"up{k + 1}.up.weight"], st[f"up{k + 1}.up.bias"], stride=2)
+        dy = skip.shape[2] - up.shape[2]
+        dx = skip.shape[3] - up.shape[3]
+        up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])                   # unet.py:57-62
+        cur = _double_conv(torch.cat([skip, up], dim=1), st, f"up{k + 1}.conv.double_conv", training)  # :66-67
+    return F.conv2d(cur, st["outc.conv.weight"], st["outc.conv.bias"])                   # unet.py:74-77
+
+
+def ce_loss(logits: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
+    """water_seg_model.py:103-106: CrossEntropyLoss(ignore_index) (mean over non-ignored pixels),
+    NaN (all pixels ignored) replaced by 0 through nan_to_num."""
+    loss = F.cross_entropy(logits, target, ignore_index=ignore_index)
+    if torch.isnan(loss):
+        loss = torch.nan_to_num(loss)
+    return loss
+
+
+def resolve_ignore_index(ignore_index: int, n_classes: int) -> int:
+    """water_seg_model.py:35-36."""
+    return n_classes - 1 if ignore_index == -1 else ignore_index
+
+
+# --------------------------------------------------------------------------- #
+# metrics (argmax confusion counters; formulas restate torchmetrics' micro average)
+# --------------------------------------------------------------------------- #
+def confusion_counts(pred: torch.Tensor, target: torch.Tensor, n_classes: int,
+                     ignore_index: Optional[int]) -> np.ndarray:
+    """[n_classes, n_classes] int64 matrix M[t, p] over pixels whose target != ignore_index."""
+    p = pred.reshape(-1).numpy().astype(np.int64)
+    t = target.reshape(-1).numpy().astype(np.int64)
+    keep = np.ones_like(t, dtype=bool) if ignore_index is None else (t != ignore_index)
+    keep &= (t >= 0) & (t < n_classes)
+    m = np.bincount(t[keep] * n_classes + p[keep], minlength=n_classes * n_classes)
+    return m.reshape(n_classes, n_classes)
+
+
+def metrics_from_counts(m: np.ndarray) -> Dict[str, float]:
+    """Micro-averaged multiclass F1 / Jaccard / Accuracy from a confusion matrix whose
+    ignored-target pixels were already dropped.  PARITY UNPINNED: torchmetrics (third
+    party, pinned 0.10.0 in environment.yml:188, code needs >=0.11) is absent here; the
+    formulas are its documented micro reductions: tp = trace, fp = fn = total - tp."""
+    tp = float(np.trace(m))
+    tot = float(m.sum())
+    fp = fn = tot - tp
+    f1 = 2 * tp / (2 * tp + fp + fn) if tot > 0 else 0.0
+    jac = tp / (tp + fp + fn) if tot > 0 else 0.0
+    acc = tp / tot if tot > 0 else 0.0
+    return {"MulticlassF1Score": f1, "MulticlassJaccardIndex": jac, "MulticlassAccuracy": acc}
+
+
+# --------------------------------------------------------------------------- #
+# training step (what Lightning's automatic optimisation does around training_step)
+# --------------------------------------------------------------------------- #
+def trainable_names(st: Dict[str, torch.Tensor], n_channels=None) -> List[str]:
+    return [k for k in st if not (k.endswith("running_mean") or k.endswith("running_var")
+                                  or k.endswith("num_batches_tracked"))]
+
+
+def new_adam_state(st: Dict[str, torch.Tensor]) -> Dict[str, object]:
+    names = trainable_names(st)
+    return {"step": 0,
+            "m": {k: torch.zeros_like(st[k]) for k in names},
+            "v": {k: torch.zeros_like(st[k]) for k in names}}
+
+
+def adam_update(st, grads, opt, lr):
+    """torch.optim.Adam single-tensor update order (water_seg_model.py:200)."""
+    opt["step"] += 1
+    t = opt["step"]
+    bc1 = 1.0 - ADAM_BETA1 ** t
+    bc2 = 1.0 - ADAM_BETA2 ** t
+    step_size = lr / bc1
+    bc2_sqrt = bc2 ** 0.5
+    for k, g in grads.items():
+        m, v = opt["m"][k], opt["v"][k]
+        m.lerp_(g, 1.0 - ADAM_BETA1)
+        v.mul_(ADAM_BETA2).addcmul_(g, g, value=1.0 - ADAM_BETA2)
+        denom = (v.sqrt() / bc2_sqrt).add_(ADAM_EPS)
+        st[k].addcdiv_(m, denom, value=-step_size)
+
+
+def loss_and_grads(st, batch, ignore_index, bilinear=True, early_fusion=False,
+                   training=True):
+    """forward + CE + autograd backward.  Returns (logits, loss, grads dict)."""
+    names = trainable_names(st)
+    leaves = {}
+    work = dict(st)
+    for k in names:
+        leaves[k] = st[k].detach().clone().requires_grad_(True)
+        work[k] = leaves[k]
+    x = assemble_input(batch, early_fusion)
+    logits = unet_forward(work, x, training, bilinear)
+    # running buffers were updated in `work` (same tensor objects as st) -> nothing to copy back
+    loss = ce_loss(logits, batch["target"], ignore_index)
+    loss.backward()
+    grads = {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k]))
+             for k in names}
+    return logits.detach(), loss.detach(), grads
+
+
+def train_step(st, opt, batch, ignore_index, lr, bilinear=True, early_fusion=False):
+    """One optimiser step: zero_grad -> training_step -> backward -> Adam.step (fit.py:95-97)."""
+    logits, loss, grads = loss_and_grads(st, batch, ignore_index, bilinear, early_fusion, True)
+    with torch.no_grad():
+        adam_update(st, grads, opt, lr)
+    return logits, loss, grads
+
+
+def eval_forward(st, batch, bilinear=True, early_fusion=False):
+    with torch.no_grad():
+        return unet_forward(dict(st), assemble_input(batch, early_fusion), False, bilinear)
+
+
+# --------------------------------------------------------------------------- #
+# algorithmic work: conv MACs x 2 only
+# --------------------------------------------------------------------------- #
+def conv_flops_per_tile(n_channels, H, W, base=64, bilinear=True, n_classes=3):
+    """(fwd_flops, train_flops) per tile; train = 3*fwd - dgrad(first conv)."""
+    enc, dec = channel_plan(n_channels, base, bilinear)
+    fwd = 0.0
+    h, w = H, W
+    sizes = [(H, W)]
+    for i in range(1, 5):
+        h, w = h // 2, w // 2
+        sizes.append((h, w))
+    first = None
+    for i, (_, cin, cmid, cout) in enumerate(enc):
+        h, w = sizes[i]
+        f1 = 2.0 * 9 * cin * cmid * h * w
+        f2 = 2.0 * 9 * cmid * cout * h * w
+        if first is None:
+            first = f1
+        fwd += f1 + f2
+    for k, (_, low, skip, mid, cout) in enumerate(dec):
+        h, w = sizes[3 - k]
+        if bilinear:
+            cin = low + skip
+        else:
+            cin = low // 2 + skip
+            hl, wl = sizes[4 - k]
+            fwd += 2.0 * 4 * low * (low // 2) * hl * wl
+        fwd += 2.0 * 9 * cin * mid * h * w + 2.0 * 9 * mid * cout * h * w
+    fwd += 2.0 * base * n_classes * H * W
+    return fwd, 3.0 * fwd - first
