@@ -1,0 +1,856 @@
+// libfloodunet: context, static execution plan of the UNet training step and the C ABI (include/floodunet.h).
+//
+// Data layout in HBM (all owned by the context, one arena allocation):
+//   activations  NHWC, element type = precision (fp32 or bf16); for every 3x3 conv only its RAW output y
+//                (pre-BatchNorm) is kept -- BN+ReLU is re-applied by whoever reads y (next conv's staging,
+//                pool, upsample, head, and the backward kernels), so normalised tensors never touch HBM.
+//   pooled[l], up[k]   the only materialised post-activation tensors (pool / bilinear outputs).
+//   gradients    one buffer per y (same shape/type): first holds dL/d relu(bn(y)), then, in place, dL/dy.
+//   parameters   caller-owned flat fp32 buffers in reference state_dict order (OIHW); the context keeps
+//                packed per-tap copies (forward and tap-reversed dgrad layouts) refreshed after each update.
+#include "../../include/floodunet.h"
+#include "fu_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace fu;
+
+namespace fu {
+
+// ---- precision dispatch -------------------------------------------------------------------------
+int conv3x3_num_stat_tiles(Prec p, int B, int H, int W) {
+  (void)p;
+  return conv3x3_num_stat_tiles_f32(B, H, W);
+}
+int launch_conv3x3(Prec p, const ConvIn& in, const void* wpk, const float* bias, void* dst0, int D0, void* dst1,
+                   int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
+  if (p == PREC_F32)
+    return launch_conv3x3_f32(in, (const float*)wpk, bias, (float*)dst0, D0, (float*)dst1, D1, stats, n_stat_tiles, B,
+                              H, W, s);
+  set_error("bf16 convolution kernels are not part of this build yet");
+  return FU_ERR_UNSUPPORTED;
+}
+int64_t conv3x3_wgrad_slab_elems(Prec p, int Cin, int Cout, int B, int H, int W) {
+  (void)p;
+  return conv3x3_wgrad_slab_elems_f32(Cin, Cout, B, H, W);
+}
+int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, float* slab, float* dw_oihw,
+                         int cin_real, const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
+                         hipStream_t s) {
+  if (p == PREC_F32)
+    return launch_conv3x3_wgrad_f32(in, (const float*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
+                                    db, B, H, W, s);
+  set_error("bf16 convolution kernels are not part of this build yet");
+  return FU_ERR_UNSUPPORTED;
+}
+int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout) {
+  (void)p;
+  return (int64_t)9 * cin_pad * Cout;
+}
+int launch_pack_conv3x3(Prec p, const float* w_oihw, int Cout, int cin_real, int cin_pad, void* wfwd, void* wdgrad,
+                        hipStream_t s) {
+  if (p == PREC_F32) return launch_pack_conv3x3_f32(w_oihw, Cout, cin_real, cin_pad, (float*)wfwd, (float*)wdgrad, s);
+  set_error("bf16 convolution kernels are not part of this build yet");
+  return FU_ERR_UNSUPPORTED;
+}
+
+}  // namespace fu
+
+// ---- plan structures ------------------------------------------------------------------------------
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+constexpr float BN_MOMENTUM = 0.1f;
+
+struct ParamInfo {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int64_t off, numel;
+};
+struct BnInfo {
+  std::string name;
+  int C;
+  int64_t off;
+};
+
+struct Conv {
+  int cin_real = 0, cin_pad = 0, cout = 0, level = 0;
+  int p_w = -1, p_b = -1, p_g = -1, p_beta = -1, bn = -1;
+  void* wf = nullptr;
+  void* wd = nullptr;
+  float *mean = nullptr, *invstd = nullptr, *a = nullptr, *b = nullptr, *coef = nullptr;
+  void* y = nullptr;
+  void* gy = nullptr;
+};
+
+enum BlockKind { BK_INC = 0, BK_DOWN = 1, BK_UP = 2 };
+
+struct Block {
+  Conv c[2];
+  int kind = BK_INC, level = 0;
+  int skip = -1;              // BK_UP: encoder block whose output is concatenated first
+  void* pooled = nullptr;     // BK_DOWN: maxpool output (input of c[0])
+  void* g_pooled = nullptr;
+  void* up = nullptr;         // BK_UP: upsampled + padded low-resolution input
+  void* g_up = nullptr;
+  UpTables upt;
+  int first_param = 0, num_params = 0;  // contiguous range in the canonical parameter table
+};
+
+struct ProfRec { int cls; double flops; hipEvent_t e0, e1; };
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;   // pairs
+  size_t next = 0;
+  std::vector<ProfRec> recs;
+  bool overflow = false;
+};
+
+struct Arena {
+  struct Req { void** slot; size_t bytes; };
+  std::vector<Req> reqs;
+  char* base = nullptr;
+  size_t total = 0;
+  template <typename T> void want(T** slot, size_t bytes) {
+    reqs.push_back({reinterpret_cast<void**>(slot), bytes});
+  }
+  int commit() {
+    size_t off = 0;
+    for (auto& r : reqs) off += (r.bytes + 255) & ~(size_t)255;
+    total = off ? off : 256;
+    FU_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base), total));
+    FU_HIP_CHECK(hipMemset(base, 0, total));
+    off = 0;
+    for (auto& r : reqs) {
+      *r.slot = base + off;
+      off += (r.bytes + 255) & ~(size_t)255;
+    }
+    return 0;
+  }
+};
+
+}  // namespace
+
+struct fu_ctx {
+  fu_config cfg;
+  Prec prec;
+  size_t esize;
+  int Hs[5], Ws[5], ch[5];
+  int cin_pad0;
+  std::vector<ParamInfo> params;
+  std::vector<BnInfo> bns;
+  int64_t total_params = 0, total_bn = 0;
+  Block blk[9];
+  int p_outw = -1, p_outb = -1;
+  // bound (caller-owned)
+  float* P = nullptr;
+  float* G = nullptr;
+  float* RM = nullptr;
+  float* RV = nullptr;
+  int64_t* NBT = nullptr;
+  bool packed_dirty = true;
+  // owned
+  Arena arena;
+  std::vector<void*> extra_allocs;
+  void* xin = nullptr;
+  float* logits = nullptr;
+  float* dlogits = nullptr;
+  float* stats = nullptr;
+  float* bnb_part = nullptr;
+  float* db_part = nullptr;
+  double* dscratch = nullptr;
+  float* slab = nullptr;
+  float* ce_part = nullptr;
+  float* hb_part = nullptr;
+  float* loss_dev = nullptr;
+  unsigned long long* conf_tmp = nullptr;
+  int64_t* n_valid = nullptr;
+  float* adam_m = nullptr;
+  float* adam_v = nullptr;
+  Profiler prof;
+  // state
+  int last_batch = 0;
+  bool fwd_training = false;
+  bool have_loss = false;
+};
+
+namespace {
+
+std::string dc_prefix(int i) {
+  if (i == 0) return "inc.double_conv";
+  if (i <= 4) return "down" + std::to_string(i) + ".maxpool_conv.1.double_conv";
+  return "up" + std::to_string(i - 4) + ".conv.double_conv";
+}
+
+int add_param(fu_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
+  ParamInfo p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int k = 0;
+  for (auto d : shape) { p.shape[k++] = d; p.numel *= d; }
+  for (; k < 4; ++k) p.shape[k] = 1;
+  p.off = c->total_params;
+  c->total_params += p.numel;
+  c->params.push_back(p);
+  return (int)c->params.size() - 1;
+}
+
+void build_axis(int in, std::vector<int>& i0, std::vector<int>& i1, std::vector<float>& w1, std::vector<int>& bo,
+                std::vector<float>& bw, bool* ok) {
+  const int out = 2 * in;
+  // ATen area_pixel_compute_scale<float>(align_corners=True) and compute_source_index_and_lambda
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  i0.resize(out); i1.resize(out); w1.resize(out);
+  bo.assign((size_t)in * UP_BWD_MAX, -1);
+  bw.assign((size_t)in * UP_BWD_MAX, 0.f);
+  std::vector<int> cnt(in, 0);
+  auto push = [&](int i, int o, float w) {
+    if (w == 0.f) return;
+    for (int j = 0; j < cnt[i]; ++j)
+      if (bo[(size_t)i * UP_BWD_MAX + j] == o) { bw[(size_t)i * UP_BWD_MAX + j] += w; return; }
+    if (cnt[i] >= UP_BWD_MAX) { *ok = false; return; }
+    bo[(size_t)i * UP_BWD_MAX + cnt[i]] = o;
+    bw[(size_t)i * UP_BWD_MAX + cnt[i]] = w;
+    cnt[i]++;
+  };
+  for (int o = 0; o < out; ++o) {
+    const float src = scale * (float)o;
+    const int a = (int)src;
+    const int off = a < in - 1 ? 1 : 0;
+    float l1 = src - (float)a;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    i0[o] = a; i1[o] = a + off; w1[o] = l1;
+    push(a, o, 1.f - l1);
+    push(a + off, o, l1);
+  }
+}
+
+template <typename T>
+int upload(fu_ctx* c, const std::vector<T>& v, const T** out) {
+  void* d = nullptr;
+  FU_HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T) + 16));
+  FU_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  c->extra_allocs.push_back(d);
+  *out = (const T*)d;
+  return 0;
+}
+
+int build_up_tables(fu_ctx* c, int H, int W, UpTables* t) {
+  std::vector<int> yi0, yi1, xi0, xi1, ybo, xbo;
+  std::vector<float> yw1, xw1, ybw, xbw;
+  bool ok = true;
+  build_axis(H, yi0, yi1, yw1, ybo, ybw, &ok);
+  build_axis(W, xi0, xi1, xw1, xbo, xbw, &ok);
+  FU_REQUIRE(ok, "bilinear backward table overflow (H=%d W=%d)", H, W);
+  FU_TRY(upload(c, yi0, &t->y_i0)); FU_TRY(upload(c, yi1, &t->y_i1)); FU_TRY(upload(c, yw1, &t->y_w1));
+  FU_TRY(upload(c, xi0, &t->x_i0)); FU_TRY(upload(c, xi1, &t->x_i1)); FU_TRY(upload(c, xw1, &t->x_w1));
+  FU_TRY(upload(c, ybo, &t->yb_o)); FU_TRY(upload(c, ybw, &t->yb_w));
+  FU_TRY(upload(c, xbo, &t->xb_o)); FU_TRY(upload(c, xbw, &t->xb_w));
+  return 0;
+}
+
+int build_plan(fu_ctx* c) {
+  const fu_config& f = c->cfg;
+  const int base = f.base_channels;
+  const int factor = f.bilinear ? 2 : 1;
+  c->ch[0] = base; c->ch[1] = base * 2; c->ch[2] = base * 4; c->ch[3] = base * 8; c->ch[4] = base * 16 / factor;
+  c->Hs[0] = f.height; c->Ws[0] = f.width;
+  for (int l = 1; l < 5; ++l) { c->Hs[l] = c->Hs[l - 1] / 2; c->Ws[l] = c->Ws[l - 1] / 2; }
+  FU_REQUIRE(c->Hs[4] >= 1 && c->Ws[4] >= 1, "tile %dx%d is too small for four 2x poolings", f.height, f.width);
+  c->cin_pad0 = round_up(f.n_channels, c->prec == PREC_F32 ? 4 : 8);
+  const int outs[4] = {base * 8 / factor, base * 4 / factor, base * 2 / factor, base};
+
+  int low = c->ch[4];
+  for (int i = 0; i < 9; ++i) {
+    Block& K = c->blk[i];
+    int cin, cmid, cout;
+    if (i == 0) { K.kind = BK_INC; K.level = 0; cin = f.n_channels; cmid = cout = c->ch[0]; }
+    else if (i <= 4) { K.kind = BK_DOWN; K.level = i; cin = c->ch[i - 1]; cmid = cout = c->ch[i]; }
+    else {
+      const int k = i - 5;
+      K.kind = BK_UP; K.skip = 3 - k; K.level = 3 - k;
+      cin = low + c->ch[3 - k]; cmid = cin / 2; cout = outs[k];
+      low = cout;
+    }
+    K.first_param = (int)c->params.size();
+    const std::string pre = dc_prefix(i);
+    for (int j = 0; j < 2; ++j) {
+      Conv& v = K.c[j];
+      v.level = K.level;
+      v.cin_real = j == 0 ? cin : cmid;
+      v.cin_pad = (i == 0 && j == 0) ? c->cin_pad0 : v.cin_real;
+      v.cout = j == 0 ? cmid : cout;
+      const std::string cn = pre + "." + std::to_string(j == 0 ? 0 : 3);
+      const std::string bn = pre + "." + std::to_string(j == 0 ? 1 : 4);
+      v.p_w = add_param(c, cn + ".weight", {v.cout, v.cin_real, 3, 3});
+      v.p_b = add_param(c, cn + ".bias", {v.cout});
+      v.p_g = add_param(c, bn + ".weight", {v.cout});
+      v.p_beta = add_param(c, bn + ".bias", {v.cout});
+      v.bn = (int)c->bns.size();
+      c->bns.push_back({bn, v.cout, c->total_bn});
+      c->total_bn += v.cout;
+    }
+    K.num_params = (int)c->params.size() - K.first_param;
+  }
+  c->p_outw = add_param(c, "outc.conv.weight", {f.n_classes, base, 1, 1});
+  c->p_outb = add_param(c, "outc.conv.bias", {f.n_classes});
+  return 0;
+}
+
+int alloc_workspace(fu_ctx* c) {
+  const fu_config& f = c->cfg;
+  const int B = f.max_batch;
+  Arena& A = c->arena;
+  const size_t es = c->esize;
+  auto act = [&](int level, int C) { return (size_t)B * c->Hs[level] * c->Ws[level] * C * es; };
+  A.want(&c->xin, act(0, c->cin_pad0));
+  int64_t max_stats = 0, max_bnb = 0, max_slab = 0, max_dbp = 0;
+  int max_c = 0;
+  for (int i = 0; i < 9; ++i) {
+    Block& K = c->blk[i];
+    for (int j = 0; j < 2; ++j) {
+      Conv& v = K.c[j];
+      const int H = c->Hs[v.level], W = c->Ws[v.level];
+      const int64_t npix = (int64_t)B * H * W;
+      A.want(&v.y, act(v.level, v.cout));
+      A.want(&v.gy, act(v.level, v.cout));
+      A.want(&v.mean, v.cout * sizeof(float));
+      A.want(&v.invstd, v.cout * sizeof(float));
+      A.want(&v.a, v.cout * sizeof(float));
+      A.want(&v.b, v.cout * sizeof(float));
+      A.want(&v.coef, v.cout * 2 * sizeof(float));
+      A.want(&v.wf, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
+      if (!(i == 0 && j == 0)) A.want(&v.wd, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
+      max_stats = std::max<int64_t>(max_stats, (int64_t)conv3x3_num_stat_tiles(c->prec, B, H, W) * v.cout * 2);
+      max_bnb = std::max<int64_t>(max_bnb, bn_bwd_partial_elems(v.cout, npix));
+      max_dbp = std::max<int64_t>(max_dbp, bn_bwd_partial_elems(v.cout, npix) / 2);
+      max_slab = std::max<int64_t>(max_slab, conv3x3_wgrad_slab_elems(c->prec, v.cin_pad, v.cout, B, H, W));
+      max_c = std::max(max_c, v.cout);
+    }
+    if (K.kind == BK_DOWN) {
+      A.want(&K.pooled, act(K.level, K.c[0].cin_real));
+      A.want(&K.g_pooled, act(K.level, K.c[0].cin_real));
+    } else if (K.kind == BK_UP) {
+      const int clow = K.c[0].cin_real - c->ch[K.skip];
+      A.want(&K.up, act(K.level, clow));
+      A.want(&K.g_up, act(K.level, clow));
+    }
+  }
+  const int64_t npix0 = (int64_t)B * f.height * f.width;
+  A.want(&c->logits, npix0 * f.n_classes * sizeof(float));
+  A.want(&c->dlogits, npix0 * f.n_classes * sizeof(float));
+  A.want(&c->stats, max_stats * sizeof(float));
+  A.want(&c->bnb_part, max_bnb * sizeof(float));
+  A.want(&c->db_part, max_dbp * sizeof(float));
+  A.want(&c->dscratch, reduce_scratch_elems(std::max(max_c, 64)) * sizeof(double));
+  A.want(&c->slab, max_slab * sizeof(float));
+  A.want(&c->ce_part, 2 * 1024 * sizeof(float));
+  A.want(&c->hb_part, head_bwd_partial_elems(f.base_channels, f.n_classes) * sizeof(float));
+  A.want(&c->loss_dev, 256);
+  A.want(&c->conf_tmp, 64 * sizeof(unsigned long long));
+  A.want(&c->n_valid, 256);
+  A.want(&c->adam_m, c->total_params * sizeof(float));
+  A.want(&c->adam_v, c->total_params * sizeof(float));
+  FU_TRY(A.commit());
+  for (int i = 5; i < 9; ++i) {
+    Block& K = c->blk[i];
+    const int lowlvl = K.level + 1;
+    FU_TRY(build_up_tables(c, c->Hs[lowlvl], c->Ws[lowlvl], &K.upt));
+  }
+  return 0;
+}
+
+// arm the event pair for the next conv / wgrad launch
+void prof_arm(fu_ctx* c, int cls, double flops) {
+  Profiler& pr = c->prof;
+  if (!pr.on) return;
+  if (pr.next + 2 > pr.pool.size()) { pr.overflow = true; return; }
+  ProfRec r{cls, flops, pr.pool[pr.next], pr.pool[pr.next + 1]};
+  pr.next += 2;
+  pr.recs.push_back(r);
+  g_prof_slot.start = r.e0;
+  g_prof_slot.stop = r.e1;
+}
+
+inline float* P(fu_ctx* c, int idx) { return c->P + c->params[idx].off; }
+inline float* G(fu_ctx* c, int idx) { return c->G + c->params[idx].off; }
+
+int repack(fu_ctx* c, hipStream_t s) {
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 2; ++j) {
+      Conv& v = c->blk[i].c[j];
+      FU_TRY(launch_pack_conv3x3(c->prec, P(c, v.p_w), v.cout, v.cin_real, v.cin_pad, v.wf, v.wd, s));
+    }
+  c->packed_dirty = false;
+  return 0;
+}
+
+ConvIn conv_input(fu_ctx* c, int i, int j) {
+  Block& K = c->blk[i];
+  ConvIn in;
+  in.src1 = nullptr; in.C1 = 0; in.a0 = nullptr; in.b0 = nullptr;
+  if (j == 1) {
+    in.src0 = K.c[0].y; in.C0 = K.c[0].cout; in.a0 = K.c[0].a; in.b0 = K.c[0].b;
+  } else if (K.kind == BK_INC) {
+    in.src0 = c->xin; in.C0 = c->cin_pad0;
+  } else if (K.kind == BK_DOWN) {
+    in.src0 = K.pooled; in.C0 = K.c[0].cin_real;
+  } else {
+    Conv& sk = c->blk[K.skip].c[1];
+    in.src0 = sk.y; in.C0 = sk.cout; in.a0 = sk.a; in.b0 = sk.b;
+    in.src1 = K.up; in.C1 = K.c[0].cin_real - sk.cout;
+  }
+  return in;
+}
+
+int conv_fwd(fu_ctx* c, int i, int j, int B, bool training, hipStream_t s) {
+  Conv& v = c->blk[i].c[j];
+  const int H = c->Hs[v.level], W = c->Ws[v.level];
+  const ConvIn in = conv_input(c, i, j);
+  int nt = 0;
+  const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
+  prof_arm(c, FU_K_CONV3X3, fl);
+  FU_TRY(launch_conv3x3(c->prec, in, v.wf, P(c, v.p_b), v.y, v.cout, nullptr, 0, training ? c->stats : nullptr, &nt, B,
+                        H, W, s));
+  const int64_t off = c->bns[v.bn].off;
+  if (training)
+    FU_TRY(launch_bn_finalize(c->stats, nt, v.cout, (int64_t)B * H * W, P(c, v.p_b), P(c, v.p_g), P(c, v.p_beta),
+                              BN_EPS, BN_MOMENTUM, v.mean, v.invstd, v.a, v.b, c->RM + off, c->RV + off,
+                              c->NBT + v.bn, c->dscratch, s));
+  else
+    FU_TRY(launch_bn_eval_coeffs(v.cout, P(c, v.p_g), P(c, v.p_beta), c->RM + off, c->RV + off, BN_EPS, v.a, v.b, s));
+  return 0;
+}
+
+int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_out, hipStream_t s) {
+  const fu_config& f = c->cfg;
+  if (c->packed_dirty) FU_TRY(repack(c, s));
+  FU_TRY(launch_nchw_to_nhwc(c->prec, x, c->xin, B, f.n_channels, f.height, f.width, c->cin_pad0, s));
+  for (int i = 0; i < 9; ++i) {
+    Block& K = c->blk[i];
+    if (K.kind == BK_DOWN) {
+      Conv& pv = c->blk[i - 1].c[1];
+      FU_TRY(launch_maxpool2(c->prec, pv.y, pv.a, pv.b, K.pooled, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout, s));
+    } else if (K.kind == BK_UP) {
+      Conv& pv = c->blk[i - 1].c[1];
+      FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout,
+                              c->Hs[K.level], c->Ws[K.level], K.upt, s));
+    }
+    FU_TRY(conv_fwd(c, i, 0, B, training, s));
+    FU_TRY(conv_fwd(c, i, 1, B, training, s));
+  }
+  Conv& last = c->blk[8].c[1];
+  FU_TRY(launch_head_fwd(c->prec, last.y, last.a, last.b, P(c, c->p_outw), P(c, c->p_outb), f.base_channels,
+                         f.n_classes, B, f.height, f.width, c->logits, logits_out, s));
+  c->last_batch = B;
+  c->fwd_training = training;
+  c->have_loss = false;
+  return 0;
+}
+
+int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
+  Block& K = c->blk[i];
+  Conv& v = K.c[j];
+  const int H = c->Hs[v.level], W = c->Ws[v.level];
+  const int64_t npix = (int64_t)B * H * W;
+  int ndb = 0;
+  // BN + ReLU backward: gy <- dL/dy ; dgamma, dbeta
+  FU_TRY(launch_bn_bwd(c->prec, v.gy, v.y, v.cout, npix, v.a, v.b, v.mean, v.invstd, P(c, v.p_g), G(c, v.p_g),
+                       G(c, v.p_beta), c->bnb_part, v.coef, c->db_part, &ndb, c->dscratch, s));
+  // weight (and bias) gradient
+  const ConvIn in = conv_input(c, i, j);
+  const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
+  prof_arm(c, FU_K_WGRAD, fl);
+  FU_TRY(launch_conv3x3_wgrad(c->prec, in, v.gy, v.cout, c->slab, G(c, v.p_w), v.cin_real, c->db_part, ndb,
+                              G(c, v.p_b), B, H, W, s));
+  // data gradient
+  if (!(i == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
+  if (j == 1) {
+    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.c[0].gy, K.c[0].cout, nullptr, 0, nullptr, nullptr, B, H, W,
+                          s));
+  } else if (K.kind == BK_DOWN) {
+    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.g_pooled, v.cin_real, nullptr, 0, nullptr, nullptr, B, H, W,
+                          s));
+    Conv& pv = c->blk[i - 1].c[1];
+    FU_TRY(launch_maxpool2_bwd(c->prec, K.g_pooled, pv.y, pv.a, pv.b, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level],
+                               pv.cout, s));
+  } else if (K.kind == BK_UP) {
+    Conv& sk = c->blk[K.skip].c[1];
+    Conv& pv = c->blk[i - 1].c[1];
+    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, sk.gy, sk.cout, K.g_up, v.cin_real - sk.cout, nullptr, nullptr,
+                          B, H, W, s));
+    FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout, H, W, K.upt, s));
+  }
+  return 0;
+}
+
+int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStream_t s) {
+  const fu_config& f = c->cfg;
+  const int B = c->last_batch;
+  if (block == 0) {
+    if (dlogits_ext)
+      FU_TRY(launch_dlogits_from_nchw(dlogits_ext, c->dlogits, f.n_classes, B, f.height, f.width, s));
+    else
+      FU_REQUIRE(c->have_loss, "fu_backward: no dlogits given and no fu_loss_* call since the last forward");
+    Conv& last = c->blk[8].c[1];
+    FU_TRY(launch_head_bwd(c->prec, c->dlogits, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
+                           (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s));
+    return 0;
+  }
+  const int i = 9 - block;
+  FU_TRY(backward_conv(c, i, 1, B, s));
+  FU_TRY(backward_conv(c, i, 0, B, s));
+  return 0;
+}
+
+int check_fwd_args(fu_ctx* c, const float* x, int batch) {
+  FU_REQUIRE(c != nullptr, "null context");
+  FU_REQUIRE(c->P && c->RM && c->RV && c->NBT, "fu_forward: buffers not bound (fu_bind_buffers)");
+  FU_REQUIRE(x != nullptr, "fu_forward: null input");
+  FU_REQUIRE(batch >= 1 && batch <= c->cfg.max_batch, "fu_forward: batch %d outside 1..%d", batch, c->cfg.max_batch);
+  return 0;
+}
+
+double conv_flops(fu_ctx* c, bool train) {
+  double fwd = 0.0, first = 0.0;
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const Conv& v = c->blk[i].c[j];
+      const double fl = 2.0 * 9 * v.cin_real * v.cout * c->Hs[v.level] * c->Ws[v.level];
+      if (i == 0 && j == 0) first = fl;
+      fwd += fl;
+    }
+  fwd += 2.0 * c->cfg.base_channels * c->cfg.n_classes * c->cfg.height * c->cfg.width;
+  return train ? 3.0 * fwd - first : fwd;
+}
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+int fu_abi_version(void) { return FU_ABI_VERSION; }
+const char* fu_last_error(void) { return get_error(); }
+
+int fu_create(const fu_config* cfg, fu_ctx** out) {
+  FU_REQUIRE(cfg && out, "fu_create: null argument");
+  FU_REQUIRE(cfg->struct_size == (int32_t)sizeof(fu_config), "fu_create: fu_config size mismatch (%d vs %zu)",
+             cfg->struct_size, sizeof(fu_config));
+  FU_REQUIRE(cfg->n_channels >= 1 && cfg->n_channels <= 64, "n_channels must be 1..64");
+  FU_REQUIRE(cfg->n_classes >= 1 && cfg->n_classes <= HEAD_MAX_CLS, "n_classes must be 1..%d", HEAD_MAX_CLS);
+  const int b = cfg->base_channels;
+  FU_REQUIRE(b == 4 || b == 8 || b == 16 || b == 32 || b == 64, "base_channels must be 4, 8, 16, 32 or 64");
+  FU_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
+  FU_REQUIRE(cfg->height >= 16 && cfg->width >= 16, "tile must be at least 16x16");
+  FU_REQUIRE(cfg->precision == FU_F32 || cfg->precision == FU_BF16, "unknown precision %d", cfg->precision);
+  if (!cfg->bilinear) {
+    set_error("bilinear=0 (ConvTranspose2d upsampling) is not implemented in this build");
+    return FU_ERR_UNSUPPORTED;
+  }
+  if (cfg->precision == FU_BF16) {
+    set_error("bf16 precision is not implemented in this build");
+    return FU_ERR_UNSUPPORTED;
+  }
+  FU_HIP_CHECK(hipSetDevice(cfg->device));
+  fu_ctx* c = new (std::nothrow) fu_ctx();
+  FU_REQUIRE(c, "out of host memory");
+  c->cfg = *cfg;
+  c->prec = cfg->precision == FU_F32 ? PREC_F32 : PREC_BF16;
+  c->esize = c->prec == PREC_F32 ? 4 : 2;
+  int st = build_plan(c);
+  if (st == 0) st = alloc_workspace(c);
+  if (st != 0) { fu_destroy(c); return st; }
+  *out = c;
+  return FU_OK;
+}
+
+int fu_destroy(fu_ctx* c) {
+  if (!c) return FU_OK;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+  if (c->arena.base) (void)hipFree(c->arena.base);
+  for (void* p : c->extra_allocs) (void)hipFree(p);
+  delete c;
+  return FU_OK;
+}
+
+int fu_num_params(const fu_ctx* c) { return c ? (int)c->params.size() : 0; }
+int64_t fu_total_param_elems(const fu_ctx* c) { return c ? c->total_params : 0; }
+int fu_param_info(const fu_ctx* c, int index, const char** name, int32_t* ndim, int64_t shape[4], int64_t* flat_offset) {
+  FU_REQUIRE(c && index >= 0 && index < (int)c->params.size(), "fu_param_info: bad index %d", index);
+  const ParamInfo& p = c->params[index];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+  if (flat_offset) *flat_offset = p.off;
+  return FU_OK;
+}
+int fu_num_bn(const fu_ctx* c) { return c ? (int)c->bns.size() : 0; }
+int64_t fu_total_bn_channels(const fu_ctx* c) { return c ? c->total_bn : 0; }
+int fu_bn_info(const fu_ctx* c, int index, const char** name, int32_t* channels, int64_t* flat_offset) {
+  FU_REQUIRE(c && index >= 0 && index < (int)c->bns.size(), "fu_bn_info: bad index %d", index);
+  if (name) *name = c->bns[index].name.c_str();
+  if (channels) *channels = c->bns[index].C;
+  if (flat_offset) *flat_offset = c->bns[index].off;
+  return FU_OK;
+}
+
+int fu_bind_buffers(fu_ctx* c, float* params, float* grads, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked) {
+  FU_REQUIRE(c && params && running_mean && running_var && num_batches_tracked, "fu_bind_buffers: null buffer");
+  c->P = params; c->G = grads; c->RM = running_mean; c->RV = running_var; c->NBT = num_batches_tracked;
+  c->packed_dirty = true;
+  return FU_OK;
+}
+int fu_params_changed(fu_ctx* c) {
+  FU_REQUIRE(c, "null context");
+  c->packed_dirty = true;
+  return FU_OK;
+}
+
+int fu_forward(fu_ctx* c, const float* x, int batch, int training, float* logits_out, fu_stream stream) {
+  FU_TRY(check_fwd_args(c, x, batch));
+  return forward_impl(c, x, batch, training != 0, logits_out, (hipStream_t)stream);
+}
+
+int fu_loss_ce(fu_ctx* c, const int64_t* target, int ignore_index, float* loss_out, int64_t* confusion_out,
+               int64_t* n_valid_out, fu_stream stream) {
+  FU_REQUIRE(c && target, "fu_loss_ce: null argument");
+  FU_REQUIRE(c->last_batch > 0, "fu_loss_ce: no forward pass yet");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)c->last_batch * c->cfg.height * c->cfg.width;
+  FU_TRY(launch_ce_loss(c->logits, target, c->cfg.n_classes, ignore_index, npix, c->ce_part,
+                        loss_out ? loss_out : c->loss_dev, c->n_valid, confusion_out, n_valid_out, c->conf_tmp, s));
+  if (c->fwd_training) {
+    FU_TRY(launch_ce_grad(c->logits, target, c->cfg.n_classes, ignore_index, npix, c->n_valid, c->dlogits, s));
+    c->have_loss = true;
+  }
+  return FU_OK;
+}
+
+int fu_loss_bce_dice(fu_ctx* c, const int64_t* target, int ignore_index, float dice_weight, float* loss_out,
+                     fu_stream stream) {
+  (void)c; (void)target; (void)ignore_index; (void)dice_weight; (void)loss_out; (void)stream;
+  set_error("fu_loss_bce_dice is not implemented in this build");
+  return FU_ERR_UNSUPPORTED;
+}
+
+int fu_num_blocks(const fu_ctx* c) { (void)c; return 10; }
+
+int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stream) {
+  FU_REQUIRE(c, "null context");
+  FU_REQUIRE(block >= 0 && block < 10, "fu_backward_block: block %d outside 0..9", block);
+  if (!(c->last_batch > 0 && c->fwd_training)) {
+    set_error("fu_backward: the last fu_forward was not a training forward");
+    return FU_ERR_STATE;
+  }
+  FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
+  return backward_block_impl(c, block, dlogits, (hipStream_t)stream);
+}
+
+int fu_backward(fu_ctx* c, const float* dlogits, fu_stream stream) {
+  for (int b = 0; b < 10; ++b) FU_TRY(fu_backward_block(c, b, dlogits, stream));
+  return FU_OK;
+}
+
+int fu_block_param_range(const fu_ctx* c, int block, int64_t* flat_offset, int64_t* numel) {
+  FU_REQUIRE(c && block >= 0 && block < 10, "fu_block_param_range: bad block %d", block);
+  int first, count;
+  if (block == 0) { first = c->p_outw; count = 2; }
+  else { const Block& K = c->blk[9 - block]; first = K.first_param; count = K.num_params; }
+  const ParamInfo& a = c->params[first];
+  const ParamInfo& z = c->params[first + count - 1];
+  if (flat_offset) *flat_offset = a.off;
+  if (numel) *numel = z.off + z.numel - a.off;
+  return FU_OK;
+}
+
+int fu_adam_step(fu_ctx* c, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                 fu_stream stream) {
+  FU_REQUIRE(c && c->P && c->G, "fu_adam_step: parameter / gradient buffers not bound");
+  FU_REQUIRE(step >= 1, "fu_adam_step: step is 1-based");
+  FU_TRY(launch_adam(c->P, c->G, c->adam_m, c->adam_v, c->total_params, lr, beta1, beta2, eps, step, grad_scale,
+                     (hipStream_t)stream));
+  c->packed_dirty = true;
+  return FU_OK;
+}
+
+int fu_adam_state(fu_ctx* c, float** exp_avg, float** exp_avg_sq) {
+  FU_REQUIRE(c, "null context");
+  if (exp_avg) *exp_avg = c->adam_m;
+  if (exp_avg_sq) *exp_avg_sq = c->adam_v;
+  return FU_OK;
+}
+
+int fu_zero_grads(fu_ctx* c, fu_stream stream) {
+  FU_REQUIRE(c && c->G, "fu_zero_grads: no gradient buffer bound");
+  FU_HIP_CHECK(hipMemsetAsync(c->G, 0, c->total_params * sizeof(float), (hipStream_t)stream));
+  return FU_OK;
+}
+
+int64_t fu_workspace_bytes(const fu_ctx* c) { return c ? (int64_t)c->arena.total : 0; }
+
+int fu_flops_per_tile(const fu_ctx* c, double* fwd, double* train) {
+  FU_REQUIRE(c, "null context");
+  if (fwd) *fwd = conv_flops(const_cast<fu_ctx*>(c), false);
+  if (train) *train = conv_flops(const_cast<fu_ctx*>(c), true);
+  return FU_OK;
+}
+
+int fu_profile_enable(fu_ctx* c, int enable) {
+  FU_REQUIRE(c, "null context");
+  Profiler& pr = c->prof;
+  if (enable) {
+    const size_t want = 2 * 8192;
+    while (pr.pool.size() < want) {
+      hipEvent_t e;
+      FU_HIP_CHECK(hipEventCreate(&e));
+      pr.pool.push_back(e);
+    }
+    pr.next = 0;
+    pr.recs.clear();
+    pr.overflow = false;
+    pr.on = true;
+  } else {
+    pr.on = false;
+  }
+  return FU_OK;
+}
+
+int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
+                    const char** kernel_name) {
+  FU_REQUIRE(c && kernel_class >= 0 && kernel_class < FU_K_NUM, "fu_profile_read: bad class %d", kernel_class);
+  FU_HIP_CHECK(hipDeviceSynchronize());
+  int64_t n = 0;
+  double ms = 0.0, fl = 0.0;
+  for (const ProfRec& r : c->prof.recs) {
+    if (r.cls != kernel_class) continue;
+    float t = 0.f;
+    FU_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t; fl += r.flops; ++n;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (kernel_name)
+    *kernel_name = kernel_class == FU_K_CONV3X3
+                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : "k_conv3x3_bf16")
+                       : (c->prec == PREC_F32 ? "k_wgrad_f32" : "k_wgrad_bf16");
+  return FU_OK;
+}
+
+// ---- single operators --------------------------------------------------------------------------------
+int fu_elem_size(int precision) { return precision == FU_F32 ? 4 : 2; }
+
+static int prec_of(int precision, Prec* p) {
+  FU_REQUIRE(precision == FU_F32 || precision == FU_BF16, "unknown precision %d", precision);
+  *p = precision == FU_F32 ? PREC_F32 : PREC_BF16;
+  return 0;
+}
+
+int fu_op_nchw_to_nhwc(int precision, const float* src, void* dst, int B, int C, int H, int W, int c_pad,
+                       fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  return launch_nchw_to_nhwc(p, src, dst, B, C, H, W, c_pad, (hipStream_t)stream);
+}
+int fu_op_nhwc_to_nchw(int precision, const void* src, float* dst, int B, int C, int H, int W, int c_pad,
+                       fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  return launch_nhwc_to_nchw(p, src, dst, B, C, H, W, c_pad, (hipStream_t)stream);
+}
+
+namespace {
+struct TmpBuf {
+  void* p = nullptr;
+  ~TmpBuf() { if (p) (void)hipFree(p); }
+  int get(size_t bytes) { FU_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return 0; }
+};
+__global__ void k_stats_collapse(const float* part, int nTiles, int C, float* sum, float* sq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int t = 0; t < nTiles; ++t) { s += part[((int64_t)t * C + c) * 2]; q += part[((int64_t)t * C + c) * 2 + 1]; }
+  sum[c] = (float)s; sq[c] = (float)q;
+}
+}  // namespace
+
+int fu_op_conv3x3_fwd(int precision, const void* src0, int C0, const float* bn_a0, const float* bn_b0,
+                      const void* src1, int C1, const float* w_oihw, const float* bias, void* y, int Cout, int B, int H,
+                      int W, float* stats_sum, float* stats_sqsum, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C0 + (src1 ? C1 : 0);
+  TmpBuf wf, st;
+  FU_TRY(wf.get(conv3x3_pack_elems(p, Cin, Cout) * fu_elem_size(precision)));
+  FU_TRY(launch_pack_conv3x3(p, w_oihw, Cout, Cin, Cin, wf.p, nullptr, s));
+  const bool want_stats = stats_sum && stats_sqsum;
+  if (want_stats) FU_TRY(st.get((size_t)conv3x3_num_stat_tiles(p, B, H, W) * Cout * 2 * sizeof(float)));
+  ConvIn in{src0, C0, bn_a0, bn_b0, src1, src1 ? C1 : 0};
+  int nt = 0;
+  FU_TRY(launch_conv3x3(p, in, wf.p, bias, y, Cout, nullptr, 0, want_stats ? (float*)st.p : nullptr, &nt, B, H, W, s));
+  if (want_stats)
+    hipLaunchKernelGGL(k_stats_collapse, dim3(ceil_div(Cout, 64)), dim3(64), 0, s, (const float*)st.p, nt, Cout,
+                       stats_sum, stats_sqsum);
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_op_conv3x3_dgrad(int precision, const void* dy, int Cout, const float* w_oihw, void* dx0, int C0, void* dx1,
+                        int C1, int B, int H, int W, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C0 + (dx1 ? C1 : 0);
+  TmpBuf wd;
+  FU_TRY(wd.get(conv3x3_pack_elems(p, Cin, Cout) * fu_elem_size(precision)));
+  FU_TRY(launch_pack_conv3x3(p, w_oihw, Cout, Cin, Cin, nullptr, wd.p, s));
+  ConvIn in{dy, Cout, nullptr, nullptr, nullptr, 0};
+  FU_TRY(launch_conv3x3(p, in, wd.p, nullptr, dx0, C0, dx1, dx1 ? C1 : 0, nullptr, nullptr, B, H, W, s));
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_op_conv3x3_wgrad(int precision, const void* src0, int C0, const float* bn_a0, const float* bn_b0,
+                        const void* src1, int C1, const void* dy, int Cout, float* dw_oihw, int B, int H, int W,
+                        fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C0 + (src1 ? C1 : 0);
+  TmpBuf slab;
+  FU_TRY(slab.get(conv3x3_wgrad_slab_elems(p, Cin, Cout, B, H, W) * sizeof(float)));
+  ConvIn in{src0, C0, bn_a0, bn_b0, src1, src1 ? C1 : 0};
+  FU_TRY(launch_conv3x3_wgrad(p, in, dy, Cout, (float*)slab.p, dw_oihw, Cin, nullptr, 0, nullptr, B, H, W, s));
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_op_maxpool2(int precision, const void* src, const float* bn_a, const float* bn_b, void* dst, int B, int H,
+                   int W, int C, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  return launch_maxpool2(p, src, bn_a, bn_b, dst, B, H, W, C, (hipStream_t)stream);
+}
+
+int fu_op_upsample2(int precision, const void* src, const float* bn_a, const float* bn_b, void* dst, int B, int H,
+                    int W, int C, int outH, int outW, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  fu_ctx tmp;  // only used as an allocation list for the tables
+  UpTables t;
+  int st = build_up_tables(&tmp, H, W, &t);
+  if (st == 0) st = launch_upsample2(p, src, bn_a, bn_b, dst, B, H, W, C, outH, outW, t, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  for (void* q : tmp.extra_allocs) (void)hipFree(q);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// Shared declarations for libfloodunet (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace fu {
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+
+enum Prec { PREC_F32 = 0, PREC_BF16 = 1 };
+
+// ---- error plumbing (thread-local message, never exceptions across the ABI) ----------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define FU_HIP_CHECK(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      ::fu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 2;                                                                              \
+    }                                                                                        \
+  } while (0)
+
+#define FU_REQUIRE(cond, ...)          \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::fu::set_error(__VA_ARGS__);    \
+      return 1;                        \
+    }                                  \
+  } while (0)
+
+#define FU_TRY(expr)           \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != 0) return _s;    \
+  } while (0)
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- device helpers -------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte access
+  __device__ static __forceinline__ void load4(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static __forceinline__ void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __device__ static __forceinline__ float load1(const float* p) { return *p; }
+  __device__ static __forceinline__ void store1(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = t;
+  }
+  __device__ static __forceinline__ float load1(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void store1(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// XCD-aware bijective remap of a linear block id: blocks b and b+8 share an XCD (observed round
+// robin), so give each XCD a contiguous chunk of the logical id space (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+#endif  // __HIPCC__
+
+// Optional event pair recorded immediately around the main kernel of the next conv / wgrad launch
+// (set by the API layer when profiling is on, cleared by the launcher).
+struct ProfSlot { hipEvent_t start = nullptr; hipEvent_t stop = nullptr; };
+extern thread_local ProfSlot g_prof_slot;
+
+// ---- kernel launchers (implemented in the .hip files) ----------------------------------------
+// All pointers are device pointers; T-typed buffers are `void*` + Prec.
+
+struct ConvIn {              // the (virtual) input of a 3x3 convolution
+  const void* src0; int C0;  // first C0 channels (skip / plain input)
+  const float* a0;           // optional BN scale for src0: x = relu(a0*src0 + b0)
+  const float* b0;
+  const void* src1; int C1;  // next C1 channels, taken as they are (may be null/0)
+};
+
+// conv as implicit GEMM: out[p][n] = sum_{tap,c} in[p+tap][c] * wpk[tap][c][n] (+bias[n])
+// wpk layout is precision specific (see the pack kernels).  Output channels [0,D0) -> dst0, [D0,D0+D1) -> dst1.
+// stats: optional [nStatTiles][N][2] partial (sum, sumsq) of the bias-free result per pixel tile;
+// *n_stat_tiles receives the number of tiles written (<= conv3x3_num_stat_tiles()).
+int conv3x3_num_stat_tiles(Prec p, int B, int H, int W);
+int launch_conv3x3(Prec p, const ConvIn& in, const void* wpk, const float* bias, void* dst0, int D0, void* dst1,
+                   int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s);
+// dW partial slabs + fixed-order reduce into fp32 OIHW (+ bias gradient from db_partials [n][Cout]).
+int64_t conv3x3_wgrad_slab_elems(Prec p, int Cin, int Cout, int B, int H, int W);
+int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, float* slab, float* dw_oihw,
+                         int cin_real, const float* db_partials, int n_db_partials, float* db, int B, int H,
+                         int W, hipStream_t s);
+
+// weight packing: fp32 OIHW [Cout][cin_real][3][3] -> fwd pack (GEMM K = cin padded to cin_pad, N = Cout)
+// and dgrad pack (taps reversed, K = Cout, N = cin_pad).  Either destination may be null.
+int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout);
+int launch_pack_conv3x3(Prec p, const float* w_oihw, int Cout, int cin_real, int cin_pad, void* wfwd, void* wdgrad,
+                        hipStream_t s);
+
+// precision-specific implementations (fu_conv_f32.hip / fu_conv_bf16.hip)
+int conv3x3_num_stat_tiles_f32(int B, int H, int W);
+int launch_conv3x3_f32(const ConvIn& in, const float* wpk, const float* bias, float* dst0, int D0, float* dst1, int D1,
+                       float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s);
+int64_t conv3x3_wgrad_slab_elems_f32(int Cin, int Cout, int B, int H, int W);
+int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float* slab, float* dw_oihw, int cin_real,
+                             const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
+                             hipStream_t s);
+int launch_pack_conv3x3_f32(const float* w_oihw, int Cout, int cin_real, int cin_pad, float* wfwd, float* wdgrad,
+                            hipStream_t s);
+
+int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s);
+int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H, int W, int c_pad, hipStream_t s);
+
+// BN: finalize forward statistics.  partials [nTiles][C][2]; count = B*H*W.
+// training: writes mean/invstd/a/b, updates running stats (momentum 0.1, unbiased var) and nbt.
+int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, const float* conv_bias,
+                       const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
+                       float* a, float* b, float* running_mean, float* running_var, int64_t* nbt, double* dscratch,
+                       hipStream_t s);
+// fp64 scratch needed by the two-level reductions: elements for a layer with C channels
+static inline int64_t reduce_scratch_elems(int C) { return (int64_t)32 * C * 2; }
+// eval: a,b from the running statistics
+int launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* a, float* b, hipStream_t s);
+// backward: g (in place -> dy).  Two launches + finalize inside.  partials scratch: >= bn_bwd_partial_elems.
+int64_t bn_bwd_partial_elems(int C, int64_t npix);
+int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
+                  const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                  float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
+                  hipStream_t s);
+
+int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                    hipStream_t s);
+// g_src[argmax] += g_dst
+int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const float* a, const float* b, void* g_src,
+                        int B, int H, int W, int C, hipStream_t s);
+
+struct UpTables {  // device tables for one bilinear x2 resize (H x W -> 2H x 2W, placed inside outH x outW)
+  const int* y_i0; const int* y_i1; const float* y_w1;  // [2H]
+  const int* x_i0; const int* x_i1; const float* x_w1;  // [2W]
+  // backward gather lists: for input index i up to UP_BWD_MAX (o, w) pairs
+  const int* yb_o; const float* yb_w;  // [H][UP_BWD_MAX]
+  const int* xb_o; const float* xb_w;  // [W][UP_BWD_MAX]
+};
+static constexpr int UP_BWD_MAX = 6;
+int launch_upsample2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                     int outH, int outW, const UpTables& t, hipStream_t s);
+int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
+                         const UpTables& t, hipStream_t s);
+
+// head: 1x1 conv + bias on relu(a*y+b); logits fp32 NHWC [npix][ncls] (+ optional NCHW copy)
+int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const float* w, const float* bias, int C,
+                    int ncls, int B, int H, int W, float* logits_nhwc, float* logits_nchw, hipStream_t s);
+static constexpr int HEAD_MAX_CLS = 8;
+// CE loss over stored logits.  partials: [nblk][2] (loss sum, valid count as float) -> finalize
+int launch_ce_loss(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                   float* partials, float* loss_out, int64_t* n_valid_dev, int64_t* confusion_accum,
+                   int64_t* n_valid_out, unsigned long long* conf_tmp /* [64], zero-initialised */, hipStream_t s);
+// dlogits (NHWC fp32) from CE: (softmax - onehot)/n_valid on valid pixels
+int launch_ce_grad(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                   const int64_t* n_valid_dev, float* dlogits_nhwc, hipStream_t s);
+int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int ncls, int B, int H, int W,
+                             hipStream_t s);
+// head backward: G[y] = dlogits * W ; dW = sum dlogits (x) z ; db = sum dlogits
+int64_t head_bwd_partial_elems(int C, int ncls);
+int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
+                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s);
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, int64_t step, float grad_scale, hipStream_t s);
+
+}  // namespace fu

@@ -1,0 +1,912 @@
+// Memory-bound kernels of the UNet training path (gfx950): layout conversion, BatchNorm statistics
+// finalisation and backward, max-pool, bilinear x2 resize, 1x1 head + cross entropy, Adam.
+// All of them are HBM-bound: 16-byte vector accesses along the NHWC channel dimension, fp32 math,
+// deterministic two-level reductions (per-block partials -> fixed-order finalisation), wave64 shuffles.
+#include "fu_common.h"
+
+#include <stdarg.h>
+
+namespace fu {
+
+// ------------------------------------------------------------------------------------------------
+// error message storage
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+thread_local ProfSlot g_prof_slot;
+
+#define FU_LAUNCH_CHECK()                                                       \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) {                                                     \
+      set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 2;                                                                 \
+    }                                                                           \
+  } while (0)
+
+static inline int grid_for(int64_t work, int block, int cap = 8192) {
+  int64_t g = ceil_div64(work, block);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW fp32 <-> NHWC T
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int C, int HW, int cpad,
+                               int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpad);
+    const int64_t bp = idx / cpad;
+    const int p = (int)(bp % HW);
+    const int64_t b = bp / HW;
+    const float v = (c < C) ? src[(b * C + c) * HW + p] : 0.f;
+    ElemIO<T>::store1(dst + idx, v);
+  }
+}
+
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int C, int HW, int cpad,
+                               int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % HW);
+    const int64_t bc = idx / HW;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    dst[idx] = ElemIO<T>::load1(src + (b * HW + p) * cpad + c);
+  }
+}
+
+int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s) {
+  const int64_t total = (int64_t)B * H * W * c_pad;
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, C, H * W, c_pad, total);
+  else
+    hipLaunchKernelGGL(k_nchw_to_nhwc<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, C, H * W, c_pad, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H, int W, int c_pad, hipStream_t s) {
+  const int64_t total = (int64_t)B * C * H * W;
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_nhwc_to_nchw<float>, dim3(g), dim3(256), 0, s, (const float*)src, dst, C, H * W, c_pad, total);
+  else
+    hipLaunchKernelGGL(k_nhwc_to_nchw<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, dst, C, H * W, c_pad,
+                       total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// two-level per-channel reduction of partials [nPart][C][NV] (fp32) -> [G][C][NV] (fp64)
+// ------------------------------------------------------------------------------------------------
+static constexpr int RED_GROUPS = 32;
+
+template <int NV>
+__global__ void k_partials_reduce(const float* __restrict__ part, double* __restrict__ out, int nPart, int C,
+                                  int perGroup) {
+  // block: 32 channels x 8 partial lanes; grid (ceil(C/32), G)
+  __shared__ double sm[8][32][NV];
+  const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g = blockIdx.y;
+  const int t0 = g * perGroup;
+  const int t1 = min(nPart, t0 + perGroup);
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  if (c < C) {
+    for (int t = t0 + j; t < t1; t += 8) {
+      const float* q = part + ((int64_t)t * C + c) * NV;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += (double)q[v];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sm[j][cl][v] = acc[v];
+  __syncthreads();
+  if (j == 0 && c < C) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      double s = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) s += sm[jj][cl][v];
+      out[((int64_t)g * C + c) * NV + v] = s;
+    }
+  }
+}
+
+// scratch for the fp64 second level lives in a static device buffer per call site (passed in)
+template <int NV>
+static int reduce_partials(const float* part, double* out, int nPart, int C, hipStream_t s, int* groups_out) {
+  int G = nPart < RED_GROUPS ? nPart : RED_GROUPS;
+  if (G < 1) G = 1;
+  const int perGroup = ceil_div(nPart, G);
+  G = ceil_div(nPart, perGroup);
+  if (G < 1) G = 1;
+  hipLaunchKernelGGL(k_partials_reduce<NV>, dim3(ceil_div(C, 32), G), dim3(256), 0, s, part, out, nPart, C, perGroup);
+  FU_LAUNCH_CHECK();
+  *groups_out = G;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm forward statistics -> coefficients
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const double* __restrict__ dpart, int G, int C, double count,
+                              const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean_o,
+                              float* __restrict__ invstd_o, float* __restrict__ a_o, float* __restrict__ b_o,
+                              float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S = 0.0, Q = 0.0;
+  for (int g = 0; g < G; ++g) {
+    S += dpart[((int64_t)g * C + c) * 2 + 0];
+    Q += dpart[((int64_t)g * C + c) * 2 + 1];
+  }
+  const double m0 = S / count;
+  double var = Q / count - m0 * m0;
+  if (var < 0.0) var = 0.0;
+  const double mean = m0 + (conv_bias ? (double)conv_bias[c] : 0.0);
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  const float a = gamma[c] * invstd;
+  mean_o[c] = meanf;
+  invstd_o[c] = invstd;
+  a_o[c] = a;
+  b_o[c] = beta[c] - meanf * a;
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * meanf;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+  if (nbt && c == 0) *nbt += 1;
+}
+
+int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, const float* conv_bias,
+                       const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
+                       float* a, float* b, float* running_mean, float* running_var, int64_t* nbt, double* dscratch,
+                       hipStream_t s) {
+  int G = 0;
+  FU_TRY(reduce_partials<2>(partials, dscratch, nTiles, C, s, &G));
+  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, s, dscratch, G, C, (double)count,
+                     conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_bn_eval_coeffs(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                 float* __restrict__ a, float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  const float aa = gamma[c] * invstd;
+  a[c] = aa;
+  b[c] = beta[c] - rm[c] * aa;
+}
+
+int launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* a, float* b, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 64)), dim3(64), 0, s, C, gamma, beta, running_mean,
+                     running_var, eps, a, b);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward.  g = dL/d relu(bn(y)) in place -> dL/dy.
+//   m = [a*y+b > 0], xh = (y-mean)*invstd
+//   s1 = sum g*m, s2 = sum g*m*xh   (dbeta, dgamma)
+//   dy = a * (g*m - s1/N - xh*s2/N)
+// ------------------------------------------------------------------------------------------------
+static constexpr int BNB_THREADS = 256;
+
+template <typename T>
+__global__ void k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y, int C, int64_t npix,
+                                const float* __restrict__ a, const float* __restrict__ b,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                float* __restrict__ partials) {
+  extern __shared__ float sm[];  // [rows][C][2]
+  const int CV = C >> 2;
+  const int rows = BNB_THREADS / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const bool active = row < rows;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (active) {
+    float av[4], bv[4], mv[4], iv[4];
+    ElemIO<float>::load4(a + cv * 4, av);
+    ElemIO<float>::load4(b + cv * 4, bv);
+    ElemIO<float>::load4(mean + cv * 4, mv);
+    ElemIO<float>::load4(invstd + cv * 4, iv);
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
+      float gv[4], yv[4];
+      ElemIO<T>::load4(g + p * C + cv * 4, gv);
+      ElemIO<T>::load4(y + p * C + cv * 4, yv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = av[j] * yv[j] + bv[j];
+        const float gm = z > 0.f ? gv[j] : 0.f;
+        s1[j] += gm;
+        s2[j] += gm * ((yv[j] - mv[j]) * iv[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sm[((row * C) + cv * 4 + j) * 2 + 0] = s1[j];
+      sm[((row * C) + cv * 4 + j) * 2 + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += BNB_THREADS) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      t1 += sm[(r * C + c) * 2 + 0];
+      t2 += sm[(r * C + c) * 2 + 1];
+    }
+    partials[((int64_t)blockIdx.x * C + c) * 2 + 0] = t1;
+    partials[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+  }
+}
+
+__global__ void k_bn_bwd_finalize(const double* __restrict__ dpart, int G, int C, double count,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S1 = 0.0, S2 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    S1 += dpart[((int64_t)g * C + c) * 2 + 0];
+    S2 += dpart[((int64_t)g * C + c) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)S1;
+  if (dgamma) dgamma[c] = (float)S2;
+  coef[c * 2 + 0] = (float)(S1 / count);
+  coef[c * 2 + 1] = (float)(S2 / count);
+}
+
+template <typename T>
+__global__ void k_bn_bwd_apply(T* __restrict__ g, const T* __restrict__ y, int C, int64_t npix,
+                               const float* __restrict__ a, const float* __restrict__ b,
+                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                               const float* __restrict__ coef, float* __restrict__ db_partials) {
+  extern __shared__ float sm[];  // [rows][C]
+  const int CV = C >> 2;
+  const int rows = BNB_THREADS / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const bool active = row < rows;
+  float sd[4] = {0, 0, 0, 0};
+  if (active) {
+    float av[4], bv[4], mv[4], iv[4], c1[4], c2[4];
+    ElemIO<float>::load4(a + cv * 4, av);
+    ElemIO<float>::load4(b + cv * 4, bv);
+    ElemIO<float>::load4(mean + cv * 4, mv);
+    ElemIO<float>::load4(invstd + cv * 4, iv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c1[j] = coef[(cv * 4 + j) * 2 + 0];
+      c2[j] = coef[(cv * 4 + j) * 2 + 1];
+    }
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
+      float gv[4], yv[4], o[4];
+      ElemIO<T>::load4(g + p * C + cv * 4, gv);
+      ElemIO<T>::load4(y + p * C + cv * 4, yv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = av[j] * yv[j] + bv[j];
+        const float gm = z > 0.f ? gv[j] : 0.f;
+        const float xh = (yv[j] - mv[j]) * iv[j];
+        o[j] = av[j] * (gm - c1[j] - xh * c2[j]);
+        sd[j] += o[j];
+      }
+      ElemIO<T>::store4(g + p * C + cv * 4, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[row * C + cv * 4 + j] = sd[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += BNB_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += sm[r * C + c];
+    db_partials[(int64_t)blockIdx.x * C + c] = t;
+  }
+}
+
+static int bn_bwd_blocks(int C, int64_t npix) {
+  const int rows = BNB_THREADS / (C >> 2);
+  int64_t nb = ceil_div64(npix, (int64_t)rows * 8);  // ~8 pixels per thread
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+int64_t bn_bwd_partial_elems(int C, int64_t npix) { return (int64_t)bn_bwd_blocks(C, npix) * C * 2; }
+
+int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
+                  const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                  float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
+                  hipStream_t s) {
+  (void)gamma;
+  FU_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: channels must be a multiple of 4 and <= 1024 (got %d)", C);
+  const int nb = bn_bwd_blocks(C, npix);
+  const int rows = BNB_THREADS / (C >> 2);
+  const size_t sh1 = (size_t)rows * C * 2 * sizeof(float);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const float*)g, (const float*)y,
+                       C, npix, a, b, mean, invstd, partials);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const bf16_t*)g,
+                       (const bf16_t*)y, C, npix, a, b, mean, invstd, partials);
+  FU_LAUNCH_CHECK();
+  int G = 0;
+  FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, s, dscratch, G, C, (double)npix,
+                     dgamma, dbeta, coef);
+  FU_LAUNCH_CHECK();
+  const size_t sh2 = (size_t)rows * C * sizeof(float);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(nb), dim3(BNB_THREADS), sh2, s, (float*)g, (const float*)y, C, npix,
+                       a, b, mean, invstd, coef, db_partials);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(nb), dim3(BNB_THREADS), sh2, s, (bf16_t*)g, (const bf16_t*)y, C,
+                       npix, a, b, mean, invstd, coef, db_partials);
+  FU_LAUNCH_CHECK();
+  *n_db_partials = nb;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2) on relu(a*y+b) (or on y as is when a == null)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_act4(const T* p, const float (&av)[4], const float (&bv)[4], bool bn,
+                                          float (&z)[4]) {
+  ElemIO<T>::load4(p, z);
+  if (bn) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = fmaxf(av[j] * z[j] + bv[j], 0.f);
+  }
+}
+
+template <typename T>
+__global__ void k_maxpool2(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
+                           T* __restrict__ dst, int H, int W, int C, int Ho, int Wo, int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int64_t bb = r / Ho;
+    float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+    const bool bn = a != nullptr;
+    if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
+    const T* base = src + ((bb * H + oy * 2) * W + ox * 2) * (int64_t)C + cv * 4;
+    float z00[4], z01[4], z10[4], z11[4], o[4];
+    load_act4<T>(base, av, bv, bn, z00);
+    load_act4<T>(base + C, av, bv, bn, z01);
+    load_act4<T>(base + (int64_t)W * C, av, bv, bn, z10);
+    load_act4<T>(base + (int64_t)W * C + C, av, bv, bn, z11);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(z00[j], z01[j]), fmaxf(z10[j], z11[j]));
+    ElemIO<T>::store4(dst + idx * 4, o);
+  }
+}
+
+// g_src[first argmax of the window] += g_dst   (ties -> first in row-major order, as ATen's max_pool2d)
+template <typename T>
+__global__ void k_maxpool2_bwd(const T* __restrict__ gdst, const T* __restrict__ ysrc, const float* __restrict__ a,
+                               const float* __restrict__ b, T* __restrict__ gsrc, int H, int W, int C, int Ho, int Wo,
+                               int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int64_t bb = r / Ho;
+    float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+    const bool bn = a != nullptr;
+    if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
+    const int64_t off = ((bb * H + oy * 2) * W + ox * 2) * (int64_t)C + cv * 4;
+    const int64_t offs[4] = {off, off + C, off + (int64_t)W * C, off + (int64_t)W * C + C};
+    float z[4][4], gv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_act4<T>(ysrc + offs[q], av, bv, bn, z[q]);
+    ElemIO<T>::load4(gdst + idx * 4, gv);
+    int arg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int am = 0;
+      float m = z[0][j];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (z[q][j] > m) { m = z[q][j]; am = q; }
+      arg[j] = am;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float cur[4];
+      ElemIO<T>::load4(gsrc + offs[q], cur);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cur[j] += (arg[j] == q) ? gv[j] : 0.f;
+      ElemIO<T>::store4(gsrc + offs[q], cur);
+    }
+  }
+}
+
+int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                    hipStream_t s) {
+  FU_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0");
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_maxpool2<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, Ho,
+                       Wo, total);
+  else
+    hipLaunchKernelGGL(k_maxpool2<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
+                       Ho, Wo, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const float* a, const float* b, void* g_src,
+                        int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_maxpool2_bwd<float>, dim3(g), dim3(256), 0, s, (const float*)g_dst, (const float*)y_src, a,
+                       b, (float*)g_src, H, W, C, Ho, Wo, total);
+  else
+    hipLaunchKernelGGL(k_maxpool2_bwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)g_dst, (const bf16_t*)y_src, a,
+                       b, (bf16_t*)g_src, H, W, C, Ho, Wo, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear x2 (align_corners=True) of relu(a*y+b), zero-padded to outH x outW (F.pad of unet.py:57-62)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_upsample2(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
+                            T* __restrict__ dst, int H, int W, int C, int outH, int outW, int py0, int px0,
+                            UpTables t, int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ox = (int)(r % outW); r /= outW;
+    const int oy = (int)(r % outH);
+    const int64_t bb = r / outH;
+    float o[4] = {0, 0, 0, 0};
+    const int uy = oy - py0, ux = ox - px0;
+    if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W) {
+      float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+      const bool bn = a != nullptr;
+      if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
+      const int y0 = t.y_i0[uy], y1 = t.y_i1[uy];
+      const int x0 = t.x_i0[ux], x1 = t.x_i1[ux];
+      const float wy1 = t.y_w1[uy], wx1 = t.x_w1[ux];
+      const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+      const T* base = src + bb * H * (int64_t)W * C + cv * 4;
+      float z00[4], z01[4], z10[4], z11[4];
+      load_act4<T>(base + ((int64_t)y0 * W + x0) * C, av, bv, bn, z00);
+      load_act4<T>(base + ((int64_t)y0 * W + x1) * C, av, bv, bn, z01);
+      load_act4<T>(base + ((int64_t)y1 * W + x0) * C, av, bv, bn, z10);
+      load_act4<T>(base + ((int64_t)y1 * W + x1) * C, av, bv, bn, z11);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = wy0 * (wx0 * z00[j] + wx1 * z01[j]) + wy1 * (wx0 * z10[j] + wx1 * z11[j]);
+    }
+    ElemIO<T>::store4(dst + idx * 4, o);
+  }
+}
+
+template <typename T>
+__global__ void k_upsample2_bwd(const T* __restrict__ gdst, T* __restrict__ gsrc, int H, int W, int C, int outH,
+                                int outW, int py0, int px0, UpTables t, int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int64_t bb = r / H;
+    float acc[4] = {0, 0, 0, 0};
+    const T* base = gdst + bb * outH * (int64_t)outW * C + cv * 4;
+    for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
+      const int oy = t.yb_o[iy * UP_BWD_MAX + jy];
+      if (oy < 0) break;
+      const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
+      for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
+        const int ox = t.xb_o[ix * UP_BWD_MAX + jx];
+        if (ox < 0) break;
+        const float w = wy * t.xb_w[ix * UP_BWD_MAX + jx];
+        float gv[4];
+        ElemIO<T>::load4(base + ((int64_t)(oy + py0) * outW + (ox + px0)) * C, gv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += w * gv[j];
+      }
+    }
+    ElemIO<T>::store4(gsrc + idx * 4, acc);
+  }
+}
+
+int launch_upsample2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                     int outH, int outW, const UpTables& t, hipStream_t s) {
+  FU_REQUIRE(C % 4 == 0, "upsample: C %% 4 != 0");
+  FU_REQUIRE(outH >= 2 * H && outW >= 2 * W, "upsample: target smaller than 2x source");
+  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+  const int64_t total = (int64_t)B * outH * outW * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_upsample2<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C,
+                       outH, outW, py0, px0, t, total);
+  else
+    hipLaunchKernelGGL(k_upsample2<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
+                       outH, outW, py0, px0, t, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
+                         const UpTables& t, hipStream_t s) {
+  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_upsample2_bwd<float>, dim3(g), dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C,
+                       outH, outW, py0, px0, t, total);
+  else
+    hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W,
+                       C, outH, outW, py0, px0, t, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: logits[p][k] = bias[k] + sum_c relu(a*y+b)[p][c] * w[k][c]      (OutConv, unet.py:74-77)
+// LPP = C/4 lanes cooperate on one pixel (16 for C = 64); partial dot products meet through wave shuffles.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_head_fwd(const T* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
+                           const float* __restrict__ w, const float* __restrict__ bias, int C, int ncls, int64_t npix,
+                           int HW, float* __restrict__ logits_nhwc, float* __restrict__ logits_nchw) {
+  const int LPP = C >> 2;  // power of two <= 16
+  const int lane_in = threadIdx.x % LPP;
+  const int ppb = blockDim.x / LPP;  // pixels per block iteration
+  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+  const bool bn = a != nullptr;
+  if (bn) { ElemIO<float>::load4(a + lane_in * 4, av); ElemIO<float>::load4(b + lane_in * 4, bv); }
+  float wv[HEAD_MAX_CLS][4];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+    if (k < ncls) ElemIO<float>::load4(w + k * C + lane_in * 4, wv[k]);
+    else wv[k][0] = wv[k][1] = wv[k][2] = wv[k][3] = 0.f;
+  }
+  const int64_t niter = ceil_div64(npix, ppb);
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+    const int64_t p = it * ppb + threadIdx.x / LPP;
+    const bool valid = p < npix;
+    float z[4] = {0, 0, 0, 0};
+    if (valid) load_act4<T>(y + p * C + lane_in * 4, av, bv, bn, z);
+    float acc[HEAD_MAX_CLS];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+      float d = z[0] * wv[k][0] + z[1] * wv[k][1] + z[2] * wv[k][2] + z[3] * wv[k][3];
+      for (int off = LPP >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      acc[k] = d;
+    }
+    if (valid && lane_in == 0) {
+#pragma unroll
+      for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+        if (k < ncls) {
+          const float v = acc[k] + bias[k];
+          logits_nhwc[p * ncls + k] = v;
+          if (logits_nchw) {
+            const int64_t bb = p / HW;
+            const int pp = (int)(p % HW);
+            logits_nchw[(bb * ncls + k) * HW + pp] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const float* w, const float* bias, int C,
+                    int ncls, int B, int H, int W, float* logits_nhwc, float* logits_nchw, hipStream_t s) {
+  const int LPP = C / 4;
+  FU_REQUIRE(C % 4 == 0 && LPP >= 1 && LPP <= 16 && (LPP & (LPP - 1)) == 0,
+             "head: base channels must be 4, 8, 16, 32 or 64 (got %d)", C);
+  FU_REQUIRE(ncls >= 1 && ncls <= HEAD_MAX_CLS, "head: n_classes must be 1..%d", HEAD_MAX_CLS);
+  const int64_t npix = (int64_t)B * H * W;
+  const int g = grid_for(npix * LPP, 256, 4096);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_head_fwd<float>, dim3(g), dim3(256), 0, s, (const float*)y, a, b, w, bias, C, ncls, npix,
+                       H * W, logits_nhwc, logits_nchw);
+  else
+    hipLaunchKernelGGL(k_head_fwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)y, a, b, w, bias, C, ncls, npix,
+                       H * W, logits_nhwc, logits_nchw);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax cross entropy with ignore_index (water_seg_model.py:40,103-107), argmax, confusion counts
+// ------------------------------------------------------------------------------------------------
+static constexpr int CE_BLOCK = 256;
+static constexpr int CE_MAX_BLOCKS = 1024;
+
+__global__ void k_ce_loss(const float* __restrict__ logits, const int64_t* __restrict__ target, int ncls,
+                          int ignore_index, int64_t npix, float* __restrict__ partials,
+                          unsigned long long* __restrict__ conf_tmp) {
+  __shared__ unsigned int hist[HEAD_MAX_CLS * HEAD_MAX_CLS];
+  __shared__ float wsum[CE_BLOCK / 64][2];
+  for (int i = threadIdx.x; i < ncls * ncls; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  float lsum = 0.f, cnt = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = target[p];
+    float z[HEAD_MAX_CLS];
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+      if (k < ncls) {
+        z[k] = logits[p * ncls + k];
+        if (z[k] > m) { m = z[k]; am = k; }
+      }
+    }
+    if (t != (int64_t)ignore_index && t >= 0 && t < ncls) {
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_MAX_CLS; ++k)
+        if (k < ncls) se += expf(z[k] - m);
+      const float lse = m + logf(se);
+      lsum += lse - z[(int)t];
+      cnt += 1.f;
+      atomicAdd(&hist[(int)t * ncls + am], 1u);
+    }
+  }
+  lsum = wave_sum(lsum);
+  cnt = wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { wsum[wave][0] = lsum; wsum[wave][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int wv = 0; wv < CE_BLOCK / 64; ++wv) { s0 += wsum[wv][0]; s1 += wsum[wv][1]; }
+    partials[blockIdx.x * 2 + 0] = s0;
+    partials[blockIdx.x * 2 + 1] = s1;
+  }
+  for (int i = threadIdx.x; i < ncls * ncls; i += blockDim.x)
+    if (hist[i]) atomicAdd(&conf_tmp[i], (unsigned long long)hist[i]);
+}
+
+__global__ void k_ce_finalize(const float* __restrict__ partials, int nblk, int ncls, float* __restrict__ loss_out,
+                              int64_t* __restrict__ n_valid_dev, unsigned long long* __restrict__ conf_tmp,
+                              int64_t* __restrict__ conf_accum, int64_t* __restrict__ n_valid_out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0, c = 0.0;
+    for (int i = 0; i < nblk; ++i) { s += (double)partials[i * 2]; c += (double)partials[i * 2 + 1]; }
+    // CrossEntropyLoss mean over non-ignored pixels; 0/0 = NaN -> nan_to_num -> 0  (water_seg_model.py:104-106)
+    const float loss = c > 0.0 ? (float)(s / c) : 0.f;
+    if (loss_out) *loss_out = loss;
+    *n_valid_dev = (int64_t)(c + 0.5);
+    if (n_valid_out) *n_valid_out = (int64_t)(c + 0.5);
+  }
+  for (int i = threadIdx.x; i < ncls * ncls; i += blockDim.x) {
+    if (conf_accum) conf_accum[i] += (int64_t)conf_tmp[i];
+    conf_tmp[i] = 0ull;
+  }
+}
+
+int launch_ce_loss(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                   float* partials, float* loss_out, int64_t* n_valid_dev, int64_t* confusion_accum,
+                   int64_t* n_valid_out, unsigned long long* conf_tmp, hipStream_t s) {
+  const int nblk = grid_for(npix, CE_BLOCK, CE_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_ce_loss, dim3(nblk), dim3(CE_BLOCK), 0, s, logits_nhwc, target, ncls, ignore_index, npix,
+                     partials, conf_tmp);
+  FU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ce_finalize, dim3(1), dim3(64), 0, s, partials, nblk, ncls, loss_out, n_valid_dev, conf_tmp,
+                     confusion_accum, n_valid_out);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_ce_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, int ncls,
+                          int ignore_index, int64_t npix, const int64_t* __restrict__ n_valid,
+                          float* __restrict__ dl) {
+  const int64_t nv = *n_valid;
+  const float inv = nv > 0 ? 1.f / (float)nv : 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = target[p];
+    const bool valid = (t != (int64_t)ignore_index && t >= 0 && t < ncls) && nv > 0;
+    float z[HEAD_MAX_CLS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k)
+      if (k < ncls) { z[k] = logits[p * ncls + k]; m = fmaxf(m, z[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k)
+      if (k < ncls) { z[k] = expf(z[k] - m); se += z[k]; }
+    const float r = 1.f / se;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k)
+      if (k < ncls) dl[p * ncls + k] = valid ? (z[k] * r - ((int)t == k ? 1.f : 0.f)) * inv : 0.f;
+  }
+}
+
+int launch_ce_grad(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                   const int64_t* n_valid_dev, float* dlogits_nhwc, hipStream_t s) {
+  const int g = grid_for(npix, 256, 4096);
+  hipLaunchKernelGGL(k_ce_grad, dim3(g), dim3(256), 0, s, logits_nhwc, target, ncls, ignore_index, npix, n_valid_dev,
+                     dlogits_nhwc);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_dlogits_from_nchw(const float* __restrict__ src, float* __restrict__ dst, int ncls, int HW,
+                                    int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % ncls);
+    const int64_t p = idx / ncls;
+    const int64_t bb = p / HW;
+    const int pp = (int)(p % HW);
+    dst[idx] = src[(bb * ncls + k) * HW + pp];
+  }
+}
+
+int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int ncls, int B, int H, int W,
+                             hipStream_t s) {
+  const int64_t total = (int64_t)B * H * W * ncls;
+  hipLaunchKernelGGL(k_dlogits_from_nchw, dim3(grid_for(total, 256)), dim3(256), 0, s, dlogits_nchw, dlogits_nhwc, ncls,
+                     H * W, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// head backward: G[p][c] = sum_k dl[p][k] w[k][c];  dW[k][c] = sum_p dl[p][k] z[p][c];  db[k] = sum_p dl[p][k]
+// ------------------------------------------------------------------------------------------------
+static constexpr int HB_BLOCKS = 512;
+
+template <typename T>
+__global__ void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y, const float* __restrict__ a,
+                           const float* __restrict__ b, const float* __restrict__ w, int C, int ncls, int64_t npix,
+                           T* __restrict__ g, float* __restrict__ partials) {
+  extern __shared__ float sm[];  // [groups][ncls*C + ncls]
+  const int LPP = C >> 2;
+  const int lane_in = threadIdx.x % LPP;
+  const int grp = threadIdx.x / LPP;
+  const int ppb = blockDim.x / LPP;
+  const int stride = ncls * C + ncls;
+  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+  const bool bn = a != nullptr;
+  if (bn) { ElemIO<float>::load4(a + lane_in * 4, av); ElemIO<float>::load4(b + lane_in * 4, bv); }
+  float wv[HEAD_MAX_CLS][4], dw[HEAD_MAX_CLS][4], db[HEAD_MAX_CLS];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+    if (k < ncls) ElemIO<float>::load4(w + k * C + lane_in * 4, wv[k]);
+    else wv[k][0] = wv[k][1] = wv[k][2] = wv[k][3] = 0.f;
+    dw[k][0] = dw[k][1] = dw[k][2] = dw[k][3] = 0.f;
+    db[k] = 0.f;
+  }
+  const int64_t niter = ceil_div64(npix, ppb);
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+    const int64_t p = it * ppb + grp;
+    if (p < npix) {
+      float z[4], o[4] = {0, 0, 0, 0};
+      load_act4<T>(y + p * C + lane_in * 4, av, bv, bn, z);
+#pragma unroll
+      for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+        if (k < ncls) {
+          const float d = dl[p * ncls + k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] += d * wv[k][j]; dw[k][j] += d * z[j]; }
+          db[k] += d;
+        }
+      }
+      ElemIO<T>::store4(g + p * C + lane_in * 4, o);
+    }
+  }
+  for (int k = 0; k < ncls; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[grp * stride + k * C + lane_in * 4 + j] = dw[k][j];
+    if (lane_in == 0) sm[grp * stride + ncls * C + k] = db[k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < stride; e += blockDim.x) {
+    float t = 0.f;
+    for (int gq = 0; gq < ppb; ++gq) t += sm[gq * stride + e];
+    partials[(int64_t)blockIdx.x * stride + e] = t;
+  }
+}
+
+__global__ void k_head_bwd_finalize(const float* __restrict__ partials, int nblk, int C, int ncls,
+                                    float* __restrict__ dw, float* __restrict__ db) {
+  const int stride = ncls * C + ncls;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= stride) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += (double)partials[(int64_t)i * stride + e];
+  if (e < ncls * C) dw[e] = (float)s;
+  else db[e - ncls * C] = (float)s;
+}
+
+int64_t head_bwd_partial_elems(int C, int ncls) { return (int64_t)HB_BLOCKS * (ncls * C + ncls); }
+
+int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
+                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s) {
+  const int LPP = C / 4;
+  const int ppb = 256 / LPP;
+  int nblk = (int)ceil_div64(npix, ppb);
+  if (nblk > HB_BLOCKS) nblk = HB_BLOCKS;
+  const int stride = ncls * C + ncls;
+  const size_t sh = (size_t)ppb * stride * sizeof(float);
+  FU_REQUIRE(sh <= 64 * 1024, "head_bwd: LDS request too large (%zu)", sh);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_head_bwd<float>, dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const float*)y, a, b, w, C, ncls,
+                       npix, (float*)g, partials);
+  else
+    hipLaunchKernelGGL(k_head_bwd<bf16_t>, dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const bf16_t*)y, a, b, w, C,
+                       ncls, npix, (bf16_t*)g, partials);
+  FU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 64)), dim3(64), 0, s, partials, nblk, C, ncls, dw, db);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor update order; water_seg_model.py:200)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float w1, float beta2, float omb2, float inv_bc2_sqrt,
+                       float eps, float neg_step, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (gi - mi);                 // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * beta2 + (omb2 * gi) * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = p[i] + neg_step * (mi / denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, int64_t step, float grad_scale, hipStream_t s) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double step_size = (double)lr / bc1;
+  const double bc2_sqrt = sqrt(bc2);
+  const float inv_bc2_sqrt = 1.0f / (float)bc2_sqrt;
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - (double)beta1),
+                     beta2, (float)(1.0 - (double)beta2), inv_bc2_sqrt, eps, (float)(-step_size), grad_scale);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace fu

@@ -1,0 +1,111 @@
+"""One-process-per-GPU data parallelism for the UNet training step (new functionality: the reference trains
+on a single device, st_water_seg/fit.py:87-88, so the semantics are defined here and in DESIGN.md):
+
+  * DDP semantics: per-rank BatchNorm statistics and per-rank 1/N_valid loss normaliser, gradients averaged
+    over ranks (sum all-reduce, 1/world folded into the Adam kernel's grad_scale).
+  * the only exchange is the gradient all-reduce over RCCL (torch.distributed backend "nccl").  Backward runs
+    block by block (fu_backward_block); as soon as the blocks of a bucket are final, the bucket -- one contiguous
+    slice of the flat gradient buffer -- is all-reduced asynchronously on RCCL's stream while the remaining
+    backward kernels keep the compute stream busy.  4 buckets for the full-width net (7.8 / 23.6 / 18.9 / 18.8 MB):
+    xGMI is point-to-point, so few large messages amortise the per-collective latency.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(block_ranges: Sequence[Tuple[int, int]], cap_bytes: int = 25 << 20,
+                 elem_bytes: int = 4) -> List[Tuple[int, int, int]]:
+    """Merge consecutive backward blocks into buckets.  block_ranges: (offset, numel) per block in backward
+    order; consecutive blocks are adjacent in the flat buffer.  Returns (last_block_index, offset, numel)."""
+    buckets: List[Tuple[int, int, int]] = []
+    cur_lo = cur_hi = None
+    for b, (off, n) in enumerate(block_ranges):
+        lo, hi = off, off + n
+        if cur_lo is None:
+            cur_lo, cur_hi = lo, hi
+        else:
+            new_lo, new_hi = min(cur_lo, lo), max(cur_hi, hi)
+            if (new_hi - new_lo) != (cur_hi - cur_lo) + n:
+                raise ValueError("backward blocks are not adjacent in the flat gradient buffer")
+            if (new_hi - new_lo) * elem_bytes > cap_bytes:
+                buckets.append((b - 1, cur_lo, cur_hi - cur_lo))
+                cur_lo, cur_hi = lo, hi
+            else:
+                cur_lo, cur_hi = new_lo, new_hi
+        if b == len(block_ranges) - 1:
+            buckets.append((b, cur_lo, cur_hi - cur_lo))
+    return buckets
+
+
+class BucketedReducer:
+    """Asynchronous bucketed sum all-reduce of a flat gradient buffer, driven by block completion."""
+
+    def __init__(self, block_ranges: Sequence[Tuple[int, int]], world_size: int, group=None,
+                 cap_bytes: int = 25 << 20):
+        self.world_size = world_size
+        self.group = group
+        self.buckets = plan_buckets(block_ranges, cap_bytes)
+        self._by_last = {last: (off, n) for last, off, n in self.buckets}
+        self._pending = []
+
+    def block_done(self, flat_grad: torch.Tensor, block: int) -> None:
+        if self.world_size <= 1 or block not in self._by_last:
+            return
+        off, n = self._by_last[block]
+        # all_reduce(async_op=True) orders itself after the work already enqueued on the current stream and
+        # runs on the process group's own stream: the next backward blocks overlap with it.
+        self._pending.append(dist.all_reduce(flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+
+    def finish(self) -> None:
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+
+
+class DataParallelTrainer:
+    """fwd + CE + block-wise bwd (+ overlapped all-reduce) + fused Adam on a HipUNet."""
+
+    def __init__(self, net, lr: float, world_size: int = 1, rank: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 group=None, cap_bytes: int = 25 << 20):
+        self.net, self.lr, self.world_size, self.rank = net, lr, world_size, rank
+        self.betas, self.eps, self.group, self.cap_bytes = betas, eps, group, cap_bytes
+        self.step_count = 0
+        self._reducer: Optional[BucketedReducer] = None
+        self._synced = False
+
+    def _sync_initial_state(self, device):
+        net = self.net
+        if not net._flat_valid:
+            net._flatten(device)
+        for t in (net._flat, net._flat_rm, net._flat_rv, net._flat_nbt):
+            dist.broadcast(t, src=0, group=self.group)
+        net._mark_dirty()
+        self._synced = True
+
+    def step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
+        from . import _lib
+        net = self.net
+        if self.world_size > 1 and not self._synced:
+            self._sync_initial_state(x.device)
+        net._forward_raw(x, True, want_logits=False)
+        loss = net._loss_raw(target, ignore_index, x.device)
+        if self.world_size <= 1:
+            net._backward_raw(None, x.device)
+        else:
+            if self._reducer is None:
+                self._reducer = BucketedReducer(net.block_ranges(), self.world_size, self.group, self.cap_bytes)
+            lib = _lib.load()
+            stream = net._stream(x.device)
+            flat = net.flat_grads()
+            for b in range(lib.fu_num_blocks(net._ctx)):
+                _lib.check(lib.fu_backward_block(net._ctx, b, None, stream))
+                self._reducer.block_done(flat, b)
+            self._reducer.finish()
+        self.step_count += 1
+        net.adam_step(self.lr, self.step_count, self.betas, self.eps, grad_scale=1.0 / self.world_size)
+        return loss

@@ -1,0 +1,356 @@
+"""HipUNet: the reference UNet (st_water_seg/models/unet.py:80-111) executed by libfloodunet.so.
+
+The module owns nn.Parameters / BN buffers with EXACTLY the reference's state_dict keys and OIHW
+shapes (``inc.double_conv.0.weight`` ... ``outc.conv.bias``), so checkpoints, ``optim.Adam(self.parameters())``
+and ``load_state_dict`` work unchanged.  All arithmetic (forward, loss, backward, optional Adam) happens in
+hand-written gfx950 kernels behind the C ABI; torch only supplies device memory, streams and autograd glue.
+
+Storage: every parameter is a view into one flat fp32 buffer in state_dict order (the same for gradients
+and BN running statistics), which is what the C side binds to and what data-parallel all-reduce buckets slice.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import _lib
+from ._lib import FuConfig, check, ptr
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter holders (names mirror nn.Conv2d / nn.BatchNorm2d inside the reference's nn.Sequential)
+# --------------------------------------------------------------------------------------------------
+class _ConvParams(nn.Module):
+    def __init__(self, cin: int, cout: int, k: int, transposed: bool = False):
+        super().__init__()
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(cout))
+        # nn.Conv2d.reset_parameters (same RNG draws, so a seeded construction matches the reference)
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        init.uniform_(self.bias, -bound, bound)
+
+
+class _BNParams(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Holder(nn.Module):
+    """Plain container; children are attached with add_module so keys match the reference."""
+
+
+def _double_conv(cin: int, cmid: int, cout: int) -> nn.Module:
+    seq = _Holder()
+    seq.add_module("0", _ConvParams(cin, cmid, 3))
+    seq.add_module("1", _BNParams(cmid))
+    seq.add_module("3", _ConvParams(cmid, cout, 3))
+    seq.add_module("4", _BNParams(cout))
+    h = _Holder()
+    h.add_module("double_conv", seq)
+    return h
+
+
+def channel_plan(n_channels: int, base: int, bilinear: bool):
+    """unet.py:88-98 generalised to base_feat_channels (unet.py:143-149,176-183)."""
+    factor = 2 if bilinear else 1
+    e = [base, base * 2, base * 4, base * 8, base * 16 // factor]
+    outs = [base * 8 // factor, base * 4 // factor, base * 2 // factor, base]
+    return e, outs
+
+
+class HipUNet(nn.Module):
+    """Drop-in for ``UNet(n_channels, n_classes, bilinear=True)`` running on MI355X HIP kernels.
+
+    precision: 'fp32' (exact-f32 MFMA; logits within 1e-4 of the reference) or 'bf16'.
+    """
+
+    def __init__(self, n_channels: int, n_classes: int, bilinear: bool = True, base_channels: int = 64,
+                 precision: str = "fp32"):
+        super().__init__()
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}")
+        self.n_channels, self.n_classes, self.bilinear = n_channels, n_classes, bilinear
+        self.base_channels, self.precision = base_channels, precision
+        e, outs = channel_plan(n_channels, base_channels, bilinear)
+        # construction order == reference (unet.py:88-98) so torch.manual_seed(s) gives identical weights
+        self.inc = _double_conv(n_channels, e[0], e[0])
+        for i in range(1, 5):
+            d = _Holder()
+            mp = _Holder()
+            mp.add_module("1", _double_conv(e[i - 1], e[i], e[i]))
+            d.add_module("maxpool_conv", mp)
+            self.add_module(f"down{i}", d)
+        low = e[4]
+        for k in range(4):
+            u = _Holder()
+            skip = e[3 - k]
+            if bilinear:
+                cin = low + skip
+                u.add_module("conv", _double_conv(cin, cin // 2, outs[k]))
+            else:
+                u.add_module("up", _ConvParams(low, low // 2, 2, transposed=True))
+                u.add_module("conv", _double_conv(low // 2 + skip, outs[k], outs[k]))
+            self.add_module(f"up{k + 1}", u)
+            low = outs[k]
+        oc = _Holder()
+        oc.add_module("conv", _ConvParams(base_channels, n_classes, 1))
+        self.outc = oc
+
+        self._table: List[Tuple[str, nn.Parameter, int, int]] = []  # name, param, offset, numel
+        off = 0
+        for name, p in self.named_parameters():
+            self._table.append((name, p, off, p.numel()))
+            off += p.numel()
+        self._total = off
+        self._bn: List[Tuple[str, _BNParams, int]] = []
+        boff = 0
+        for name, m in self.named_modules():
+            if isinstance(m, _BNParams):
+                self._bn.append((name, m, boff))
+                boff += m.weight.numel()
+        self._total_bn = boff
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._flat_rm = self._flat_rv = self._flat_nbt = None
+        self._flat_valid = False
+        self._ctx = None
+        self._ctx_key = None
+        self._eval_dirty = True
+        self._confusion: Optional[torch.Tensor] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+
+    # ---------------------------------------------------------------- flat storage
+    def _mark_dirty(self):
+        self._eval_dirty = True
+
+    def _apply(self, fn, *args, **kwargs):
+        self._flat_valid = False
+        self._eval_dirty = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def _flatten(self, device: torch.device):
+        with torch.no_grad():
+            flat = torch.empty(self._total, dtype=torch.float32, device=device)
+            for _, p, off, n in self._table:
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+            rm = torch.empty(self._total_bn, dtype=torch.float32, device=device)
+            rv = torch.empty(self._total_bn, dtype=torch.float32, device=device)
+            nbt = torch.empty(len(self._bn), dtype=torch.int64, device=device)
+            for i, (_, m, off) in enumerate(self._bn):
+                c = m.weight.numel()
+                rm[off:off + c].copy_(m.running_mean)
+                rv[off:off + c].copy_(m.running_var)
+                nbt[i].copy_(m.num_batches_tracked)
+                m.running_mean = rm[off:off + c]
+                m.running_var = rv[off:off + c]
+                m.num_batches_tracked = nbt[i]
+            self._flat, self._flat_rm, self._flat_rv, self._flat_nbt = flat, rm, rv, nbt
+            self._flat_grad = torch.zeros(self._total, dtype=torch.float32, device=device)
+        self._flat_valid = True
+        self._destroy_ctx()
+
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat
+
+    def flat_grads(self) -> torch.Tensor:
+        return self._flat_grad
+
+    def grad_views(self) -> List[torch.Tensor]:
+        g = self._flat_grad
+        return [g[off:off + n].view(p.shape) for _, p, off, n in self._table]
+
+    def attach_grads(self):
+        """Point every parameter's .grad at its slice of the flat gradient buffer."""
+        for (_, p, off, n), gv in zip(self._table, self.grad_views()):
+            p.grad = gv
+
+    # ---------------------------------------------------------------- context
+    def _destroy_ctx(self):
+        if self._ctx is not None:
+            _lib.load().fu_destroy(self._ctx)
+            self._ctx = None
+            self._ctx_key = None
+
+    def __del__(self):
+        try:
+            self._destroy_ctx()
+        except Exception:
+            pass
+
+    def _get_ctx(self, device: torch.device, B: int, H: int, W: int):
+        if device.type != "cuda":
+            raise RuntimeError("HipUNet runs only on a ROCm GPU (device type 'cuda'); there is no CPU fallback")
+        if not self._flat_valid or self._flat is None or self._flat.device != device:
+            self._flatten(device)
+        key = (device.index, H, W)
+        if self._ctx is not None and self._ctx_key[:3] == key and self._ctx_key[3] >= B:
+            return self._ctx
+        self._destroy_ctx()
+        lib = _lib.load()
+        cfg = FuConfig(C.sizeof(FuConfig), self.n_channels, self.n_classes, self.base_channels, int(self.bilinear),
+                       B, H, W, _lib.PRECISIONS[self.precision], device.index if device.index is not None else 0)
+        h = C.c_void_p()
+        check(lib.fu_create(C.byref(cfg), C.byref(h)))
+        self._ctx = h
+        self._ctx_key = key + (B,)
+        self._verify_table()
+        check(lib.fu_bind_buffers(h, ptr(self._flat), ptr(self._flat_grad), ptr(self._flat_rm), ptr(self._flat_rv),
+                                  ptr(self._flat_nbt)))
+        self._eval_dirty = True
+        return h
+
+    def _verify_table(self):
+        lib = _lib.load()
+        n = lib.fu_num_params(self._ctx)
+        if n != len(self._table) or lib.fu_total_param_elems(self._ctx) != self._total:
+            raise RuntimeError("parameter table mismatch between HipUNet and libfloodunet")
+        name = C.c_char_p()
+        ndim = C.c_int32()
+        shape = (C.c_int64 * 4)()
+        off = C.c_int64()
+        for i, (pname, p, poff, _) in enumerate(self._table):
+            check(lib.fu_param_info(self._ctx, i, C.byref(name), C.byref(ndim), shape, C.byref(off)))
+            if name.value.decode() != pname or off.value != poff or tuple(shape[:ndim.value]) != tuple(p.shape):
+                raise RuntimeError(f"parameter {i}: python {pname}{tuple(p.shape)}@{poff} vs C "
+                                   f"{name.value.decode()}{tuple(shape[:ndim.value])}@{off.value}")
+
+    @staticmethod
+    def _stream(device) -> int:
+        return torch.cuda.current_stream(device).cuda_stream
+
+    # ---------------------------------------------------------------- raw calls
+    def _forward_raw(self, x: torch.Tensor, training: bool, want_logits: bool = True) -> Optional[torch.Tensor]:
+        if x.dim() != 4 or x.shape[1] != self.n_channels:
+            raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        B, _, H, W = x.shape
+        ctx = self._get_ctx(x.device, B, H, W)
+        lib = _lib.load()
+        if training or self._eval_dirty:
+            check(lib.fu_params_changed(ctx))
+            self._eval_dirty = training  # a training step is followed by an optimiser update
+        logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
+        check(lib.fu_forward(ctx, ptr(x), B, int(training), ptr(logits), self._stream(x.device)))
+        return logits
+
+    def _loss_raw(self, target: torch.Tensor, ignore_index: int, device) -> torch.Tensor:
+        lib = _lib.load()
+        target = target.contiguous().long()
+        loss = torch.empty((), dtype=torch.float32, device=device)
+        if self._confusion is None or self._confusion.device != device:
+            self._confusion = torch.zeros(self.n_classes * self.n_classes, dtype=torch.int64, device=device)
+        check(lib.fu_loss_ce(self._ctx, ptr(target), int(ignore_index), ptr(loss), ptr(self._confusion), None,
+                             self._stream(device)))
+        return loss
+
+    def _backward_raw(self, dlogits: Optional[torch.Tensor], device):
+        check(_lib.load().fu_backward(self._ctx, ptr(dlogits), self._stream(device)))
+
+    def pop_confusion(self) -> Optional[torch.Tensor]:
+        """[n_classes, n_classes] int64 confusion counts (target row, argmax column) accumulated by the fused
+        loss calls since the last pop."""
+        if self._confusion is None:
+            return None
+        out = self._confusion.view(self.n_classes, self.n_classes).clone()
+        self._confusion.zero_()
+        return out
+
+    # ---------------------------------------------------------------- public API
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """logits = UNet(x).  Differentiable w.r.t. the parameters when grad mode is on and the module trains."""
+        if self.training and torch.is_grad_enabled():
+            params = [p for _, p, _, _ in self._table]
+            return _UNetFn.apply(self, x, *params)
+        return self._forward_raw(x, self.training)
+
+    def loss(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int,
+             return_logits: bool = False):
+        """Fused forward + CrossEntropyLoss(ignore_index) (+ NaN guard) of water_seg_model.py:101-106.
+        The returned loss is differentiable: ``loss.backward()`` runs the HIP backward."""
+        if self.training and torch.is_grad_enabled():
+            params = [p for _, p, _, _ in self._table]
+            out = _UNetLossFn.apply(self, x, target, int(ignore_index), bool(return_logits), *params)
+            return out if return_logits else out[0]
+        logits = self._forward_raw(x, self.training, want_logits=return_logits)
+        loss = self._loss_raw(target, ignore_index, x.device)
+        return (loss, logits) if return_logits else loss
+
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
+        """forward + loss + backward without autograd; gradients land in the flat buffer / p.grad."""
+        self._forward_raw(x, True, want_logits=False)
+        loss = self._loss_raw(target, ignore_index, x.device)
+        self._backward_raw(None, x.device)
+        self.attach_grads()
+        return loss
+
+    def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        """Native fused Adam on the flat buffers (torch.optim.Adam semantics, water_seg_model.py:200)."""
+        dev = self._flat.device
+        check(_lib.load().fu_adam_step(self._ctx, lr, betas[0], betas[1], eps, step, grad_scale, self._stream(dev)))
+
+    def flops_per_tile(self) -> Tuple[float, float]:
+        f, t = C.c_double(), C.c_double()
+        check(_lib.load().fu_flops_per_tile(self._ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def block_ranges(self) -> List[Tuple[int, int]]:
+        """(offset, numel) of each backward block's gradients in the flat buffer, in backward order."""
+        lib = _lib.load()
+        out = []
+        o, n = C.c_int64(), C.c_int64()
+        for b in range(lib.fu_num_blocks(self._ctx)):
+            check(lib.fu_block_param_range(self._ctx, b, C.byref(o), C.byref(n)))
+            out.append((o.value, n.value))
+        return out
+
+
+class _UNetFn(torch.autograd.Function):
+    """logits = f(x; params): forward through fu_forward, backward through fu_backward(dlogits)."""
+
+    @staticmethod
+    def forward(ctx, module: HipUNet, x, *params):
+        ctx.module = module
+        ctx.device = x.device
+        return module._forward_raw(x, True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.module
+        m._backward_raw(dlogits.contiguous().float(), ctx.device)
+        return (None, None) + tuple(g.clone() for g in m.grad_views())
+
+
+class _UNetLossFn(torch.autograd.Function):
+    """(loss, logits) = CE(f(x; params), target): the fused training_step path."""
+
+    @staticmethod
+    def forward(ctx, module: HipUNet, x, target, ignore_index, want_logits, *params):
+        ctx.module = module
+        ctx.device = x.device
+        logits = module._forward_raw(x, True, want_logits=want_logits)
+        loss = module._loss_raw(target, ignore_index, x.device)
+        if logits is None:
+            logits = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        m = ctx.module
+        m._backward_raw(None, ctx.device)
+        grads = tuple(g * dloss for g in m.grad_views())
+        return (None, None, None, None, None) + grads

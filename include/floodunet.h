@@ -1,0 +1,184 @@
+/*
+ * floodunet.h -- C ABI of libfloodunet.so: the MI355X (gfx950) UNet segmentation training
+ * path of the FloodPlanet st_water_seg pipeline.
+ *
+ * The reference has no native layer: its hot path is torch.nn modules driven by Lightning
+ * ("C ABI (new; nothing to mirror in the reference)").  Each entry
+ * point below therefore cites the *Python* call it replaces (paths relative to the
+ * reference checkout):
+ *
+ *   fu_create / fu_destroy      UNet(n_channels, n_classes, bilinear)        st_water_seg/models/unet.py:80-98
+ *                               built by WaterSegmentationModel._build_model st_water_seg/models/water_seg_model.py:79-85
+ *   fu_param_info / fu_bind_*   UNet.state_dict() / .parameters()            (state-dict keys of unet.py:6-98)
+ *   fu_forward                  UNet.forward                                 st_water_seg/models/unet.py:100-111
+ *                               (train: nn.BatchNorm2d batch statistics; eval: running statistics,
+ *                                water_seg_model.py:92-96)
+ *   fu_loss_ce                  nn.CrossEntropyLoss(ignore_index) + nan_to_num + argmax + metric counts
+ *                                                                            st_water_seg/models/water_seg_model.py:40,103-113
+ *   fu_backward[_block]         loss.backward() issued by Lightning's automatic optimisation
+ *                                                                            st_water_seg/fit.py:95-97
+ *   fu_adam_step                optim.Adam(self.parameters(), lr).step()     st_water_seg/models/water_seg_model.py:198-205
+ *   fu_block_param_range        (new) gradient bucket of one backward block, for RCCL all-reduce overlap
+ *   fu_op_*                     single operators for per-op parity tests (conv2d, batch_norm, max_pool2d,
+ *                               upsample, cross_entropy as used in unet.py / water_seg_model.py)
+ *
+ * Conventions
+ *   - every pointer argument that carries tensor data is a DEVICE pointer owned by the caller
+ *     (borrowed for the duration of the call); the context owns workspaces and saved activations.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void* so that this header
+ *     needs no HIP include); nothing synchronises the device unless documented.
+ *   - every function returns FU_OK (0) or an error code; fu_last_error() returns a thread-local
+ *     message.  No C++ exception crosses this boundary.
+ *   - one context per device per process; calls on one context must be serialised by the caller.
+ */
+#ifndef FLOODUNET_H_
+#define FLOODUNET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FU_ABI_VERSION 1
+
+typedef struct fu_ctx fu_ctx;
+typedef void* fu_stream; /* hipStream_t */
+
+enum fu_status {
+  FU_OK = 0,
+  FU_ERR_INVALID = 1,     /* bad argument / shape */
+  FU_ERR_HIP = 2,         /* a HIP runtime call failed */
+  FU_ERR_STATE = 3,       /* call order violated (e.g. backward before forward) */
+  FU_ERR_UNSUPPORTED = 4  /* valid request this build does not implement */
+};
+
+enum fu_precision {
+  FU_F32 = 0, /* fp32 storage, fp32 MFMA (exact fmaf chains): the 1e-4 parity mode */
+  FU_BF16 = 1 /* bf16 activations/weights, fp32 accumulate, fp32 master weights / BN / loss */
+};
+
+enum fu_loss_kind {
+  FU_LOSS_CE = 0,      /* softmax cross entropy with ignore_index (the reference's loss) */
+  FU_LOSS_BCE_DICE = 1 /* north-star extension: per-pixel BCE + soft Dice on class 1 (parity unpinned) */
+};
+
+typedef struct fu_config {
+  int32_t struct_size;   /* = sizeof(fu_config) */
+  int32_t n_channels;    /* sum of in_channels.values() (water_seg_model.py:81-84) */
+  int32_t n_classes;     /* 3 for FloodPlanet (datasets/floodplanet.py:63) */
+  int32_t base_channels; /* 64 = UNet; other widths = UNetEncoder/Decoder(base_feat_channels) */
+  int32_t bilinear;      /* 1 = nn.Upsample(bilinear, align_corners=True) (default), 0 = ConvTranspose2d */
+  int32_t max_batch;     /* workspace is sized for this many tiles */
+  int32_t height, width; /* tile size (any size >= 16; odd sizes take the F.pad path of unet.py:57-62) */
+  int32_t precision;     /* enum fu_precision */
+  int32_t device;        /* HIP device ordinal */
+} fu_config;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int fu_abi_version(void);
+const char* fu_last_error(void);
+int fu_create(const fu_config* cfg, fu_ctx** out);
+int fu_destroy(fu_ctx* ctx);
+
+/* ---- parameter table (canonical = reference state_dict order) ----------------------------- */
+int fu_num_params(const fu_ctx* ctx);        /* trainable tensors (74 for the bilinear net) */
+int64_t fu_total_param_elems(const fu_ctx* ctx);
+/* name: state-dict key without the Lightning "model." prefix; shape: up to 4 dims (OIHW for convs);
+ * flat_offset: element offset inside the flat parameter / gradient buffers. */
+int fu_param_info(const fu_ctx* ctx, int index, const char** name, int32_t* ndim, int64_t shape[4],
+                  int64_t* flat_offset);
+int fu_num_bn(const fu_ctx* ctx);            /* BatchNorm2d layers (18) */
+int64_t fu_total_bn_channels(const fu_ctx* ctx);
+/* name: key prefix of the BN module ("inc.double_conv.1"); offset into the flat running buffers */
+int fu_bn_info(const fu_ctx* ctx, int index, const char** name, int32_t* channels, int64_t* flat_offset);
+
+/* Bind caller-owned flat device buffers.  params/grads: fp32 [fu_total_param_elems];
+ * running_mean/running_var: fp32 [fu_total_bn_channels]; num_batches_tracked: int64 [fu_num_bn].
+ * grads may be NULL for inference-only use. */
+int fu_bind_buffers(fu_ctx* ctx, float* params, float* grads, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked);
+/* Tell the context the bound parameters were modified by someone else (torch optimiser,
+ * load_state_dict): device-side packed copies are refreshed on the next forward. */
+int fu_params_changed(fu_ctx* ctx);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* x: fp32 NCHW [batch, n_channels, height, width].  logits_out: fp32 NCHW [batch, n_classes, H, W] or NULL.
+ * training != 0: batch-statistics BN, running buffers updated, activations kept for backward. */
+int fu_forward(fu_ctx* ctx, const float* x, int batch, int training, float* logits_out, fu_stream stream);
+
+/* Loss on the logits of the last fu_forward.  target: int64 [batch, H, W].
+ * loss_out: device fp32 scalar (mean over non-ignored pixels; 0 when every pixel is ignored).
+ * confusion_out: optional device int64 [n_classes*n_classes], M[t*n_classes+p] over non-ignored pixels
+ * (argmax prediction), ADDED to the existing contents.  n_valid_out: optional device int64 scalar. */
+int fu_loss_ce(fu_ctx* ctx, const int64_t* target, int ignore_index, float* loss_out, int64_t* confusion_out,
+               int64_t* n_valid_out, fu_stream stream);
+/* North-star extension (no reference counterpart): BCE on softmax p(class 1) + soft Dice, fp32 reductions. */
+int fu_loss_bce_dice(fu_ctx* ctx, const int64_t* target, int ignore_index, float dice_weight, float* loss_out,
+                     fu_stream stream);
+
+/* Backward of everything enqueued by the last training fu_forward.  dlogits: fp32 NCHW gradient w.r.t.
+ * the logits, or NULL to use the gradient of the last fu_loss_* call.  Gradients are written
+ * (not accumulated) into the bound flat gradient buffer. */
+int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
+/* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
+ * 9 = inc.  After block k returns, the gradient range fu_block_param_range(k) is final on `stream`. */
+int fu_num_blocks(const fu_ctx* ctx);
+int fu_backward_block(fu_ctx* ctx, int block, const float* dlogits, fu_stream stream);
+int fu_block_param_range(const fu_ctx* ctx, int block, int64_t* flat_offset, int64_t* numel);
+
+/* torch.optim.Adam semantics on the bound flat buffers (m, v owned by the context).
+ * step is 1-based.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int fu_adam_step(fu_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                 fu_stream stream);
+int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* device pointers, for checkpoints */
+int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+int64_t fu_workspace_bytes(const fu_ctx* ctx);
+/* algorithmic conv FLOPs of one tile: forward, and forward+backward */
+int fu_flops_per_tile(const fu_ctx* ctx, double* fwd, double* train);
+
+/* ---- profiling: HIP events around the convolution kernels (bench.py's roofline object) -------- */
+enum fu_kernel_class {
+  FU_K_CONV3X3 = 0, /* implicit-GEMM 3x3 conv kernel: forward and dgrad launches */
+  FU_K_WGRAD = 1,   /* weight-gradient kernel (without its slab reduce) */
+  FU_K_NUM = 2
+};
+/* enable != 0: allocate/reset the event pool and time every launch of the classes above on the stream it is
+ * launched on; enable == 0: stop.  fu_profile_read synchronises the device and sums what was recorded. */
+int fu_profile_enable(fu_ctx* ctx, int enable);
+int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
+                    const char** kernel_name);
+
+/* ---- single operators (per-op parity tests; NHWC device buffers of the context's precision) -- */
+/* element size of the activation type for `precision` */
+int fu_elem_size(int precision);
+/* fp32 NCHW -> NHWC (channels zero-padded to c_pad) and back (drops padding) */
+int fu_op_nchw_to_nhwc(int precision, const float* src, void* dst, int B, int C, int H, int W, int c_pad,
+                       fu_stream stream);
+int fu_op_nhwc_to_nchw(int precision, const void* src, float* dst, int B, int C, int H, int W, int c_pad,
+                       fu_stream stream);
+/* y = conv3x3(cat(relu(a0*src0+b0) or src0, src1), w) + bias; w: fp32 OIHW [Cout, C0+C1, 3, 3].
+ * stats_sum/stats_sqsum: optional fp32 [Cout] outputs (per-channel sum / sum of squares of y - bias). */
+int fu_op_conv3x3_fwd(int precision, const void* src0, int C0, const float* bn_a0, const float* bn_b0,
+                      const void* src1, int C1, const float* w_oihw, const float* bias, void* y, int Cout, int B,
+                      int H, int W, float* stats_sum, float* stats_sqsum, fu_stream stream);
+/* dx = conv3x3_transpose(dy, w): dx0 gets input channels [0,C0), dx1 gets [C0,C0+C1) */
+int fu_op_conv3x3_dgrad(int precision, const void* dy, int Cout, const float* w_oihw, void* dx0, int C0, void* dx1,
+                        int C1, int B, int H, int W, fu_stream stream);
+/* dw (fp32 OIHW) = sum_p x[p+tap] * dy[p], x assembled exactly as in fu_op_conv3x3_fwd */
+int fu_op_conv3x3_wgrad(int precision, const void* src0, int C0, const float* bn_a0, const float* bn_b0,
+                        const void* src1, int C1, const void* dy, int Cout, float* dw_oihw, int B, int H, int W,
+                        fu_stream stream);
+int fu_op_maxpool2(int precision, const void* src, const float* bn_a, const float* bn_b, void* dst, int B, int H,
+                   int W, int C, fu_stream stream);
+/* bilinear x2, align_corners=True, result zero-padded (F.pad) to [outH, outW] */
+int fu_op_upsample2(int precision, const void* src, const float* bn_a, const float* bn_b, void* dst, int B, int H,
+                    int W, int C, int outH, int outW, fu_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOODUNET_H_ */

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/floodunet.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from floodplanet_code_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "floodunet.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exists_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "libfloodunet.so missing: run __graft_entry__.build()"
+    lib = _lib.load()
+    assert lib.fu_abi_version() == 1
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    decl = declared_symbols()
+    assert len(decl) >= 30
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in floodunet.h but not exported"
+    assert set(decl) == set(_lib.SIGNATURES), (set(decl) ^ set(_lib.SIGNATURES))
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = _lib.FuConfig(0, 8, 3, 64, 1, 1, 64, 64, 0, 0)  # wrong struct_size
+    st = lib.fu_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert st == _lib.FU_ERR_INVALID and b"size mismatch" in lib.fu_last_error()
+    cfg = _lib.FuConfig(ctypes.sizeof(_lib.FuConfig), 8, 3, 48, 1, 1, 64, 64, 0, 0)  # bad base width
+    assert lib.fu_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.FU_ERR_INVALID
+    with pytest.raises(_lib.FloodUNetError):
+        _lib.check(lib.fu_param_info(None, 0, None, None, None, None))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfloodunet.so")
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        _lib.load()

@@ -1,0 +1,154 @@
+"""GPU: single HIP operators (through the C ABI's fu_op_* entry points) against torch-CPU fp32 references of
+the same op as used in unet.py (F.conv2d / batch-norm+relu prologue / max_pool2d / bilinear upsample)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from floodplanet_code_amd import _lib
+from floodplanet_code_amd._lib import check, ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32 = _lib.FU_F32
+
+
+def nhwc(x):  # [B,C,H,W] cpu -> device NHWC
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(x):  # device NHWC -> cpu [B,C,H,W]
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+CONV_SHAPES = [
+    # B, C0, C1, Cout, H, W, bn_prologue
+    (2, 8, 0, 24, 20, 37, False),
+    (1, 64, 64, 64, 32, 32, True),
+    (2, 4, 0, 4, 16, 16, True),
+    (1, 16, 8, 40, 9, 11, True),
+    (2, 128, 0, 72, 18, 18, False),
+    (3, 32, 32, 128, 64, 64, True),
+]
+
+
+def make_conv_case(B, C0, C1, Cout, H, W, bn, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    a = (torch.rand(C0, generator=g) + 0.5) if bn else None
+    b = (torch.randn(C0, generator=g) * 0.3) if bn else None
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (3.0 * (C0 + C1) ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = torch.relu(x0 * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if bn else x0
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+    return x0, x1, a, b, w, bias, xin
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_forward_and_stats(shape):
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, xin = make_conv_case(*shape)
+    ref = F.conv2d(xin, w, bias, padding=1)
+    d0 = nhwc(x0)
+    d1 = nhwc(x1) if x1 is not None else None
+    da = a.to(DEV) if bn else None
+    db = b.to(DEV) if bn else None
+    y = torch.empty(B, H, W, Cout, device=DEV)
+    ssum = torch.empty(Cout, device=DEV)
+    ssq = torch.empty(Cout, device=DEV)
+    check(lib.fu_op_conv3x3_fwd(F32, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(w.to(DEV)), ptr(bias.to(DEV)),
+                                ptr(y), Cout, B, H, W, ptr(ssum), ptr(ssq), stream()))
+    torch.cuda.synchronize()
+    out = nchw(y)
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    nb = ref - bias.view(1, -1, 1, 1)
+    assert rel_err(ssum.cpu(), nb.sum((0, 2, 3))) < 1e-4 or (ssum.cpu() - nb.sum((0, 2, 3))).abs().max() < 1e-3
+    assert rel_err(ssq.cpu(), (nb * nb).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_dgrad(shape):
+    B, C0, C1, Cout, H, W, _ = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 3.0
+    ref = torch.nn.grad.conv2d_input((B, C0 + C1, H, W), w, dy, padding=1)
+    dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV)
+    dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV) if C1 else None
+    check(lib.fu_op_conv3x3_dgrad(F32, ptr(nhwc(dy)), Cout, ptr(w.to(DEV)), ptr(dx0), C0, ptr(dx1), C1, B, H, W,
+                                  stream()))
+    torch.cuda.synchronize()
+    got = nchw(dx0) if dx1 is None else torch.cat([nchw(dx0), nchw(dx1)], 1)
+    assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_wgrad(shape):
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, xin = make_conv_case(*shape, seed=2)
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(xin, w.shape, dy, padding=1)
+    dw = torch.full(w.shape, float("nan"), device=DEV)
+    check(lib.fu_op_conv3x3_wgrad(F32, ptr(nhwc(x0)), C0, ptr(a.to(DEV)) if bn else None,
+                                  ptr(b.to(DEV)) if bn else None, ptr(nhwc(x1)) if x1 is not None else None, C1,
+                                  ptr(nhwc(dy)), Cout, ptr(dw), B, H, W, stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,H,W,bn", [(2, 8, 16, 16, True), (1, 64, 37, 45, True), (2, 4, 9, 8, False)])
+def test_maxpool(B, C, H, W, bn):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=g)
+    a = torch.rand(C, generator=g) + 0.5
+    b = torch.randn(C, generator=g) * 0.2
+    z = torch.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if bn else x
+    ref = F.max_pool2d(z, 2)
+    out = torch.empty(B, H // 2, W // 2, C, device=DEV)
+    check(lib.fu_op_maxpool2(F32, ptr(nhwc(x)), ptr(a.to(DEV)) if bn else None, ptr(b.to(DEV)) if bn else None,
+                             ptr(out), B, H, W, C, stream()))
+    torch.cuda.synchronize()
+    assert (nchw(out) - ref).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("B,C,H,W,oh,ow", [(2, 8, 16, 16, 32, 32), (1, 16, 4, 5, 9, 11), (2, 4, 1, 2, 2, 5),
+                                           (1, 64, 18, 18, 37, 37)])
+def test_upsample_bilinear_align_corners_with_pad(B, C, H, W, oh, ow):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dy, dx = oh - up.shape[2], ow - up.shape[3]
+    ref = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    out = torch.full((B, oh, ow, C), float("nan"), device=DEV)
+    check(lib.fu_op_upsample2(F32, ptr(nhwc(x)), None, None, ptr(out), B, H, W, C, oh, ow, stream()))
+    torch.cuda.synchronize()
+    assert (nchw(out) - ref).abs().max().item() < 2e-6
+
+
+def test_layout_roundtrip():
+    lib = _lib.load()
+    x = torch.randn(2, 9, 13, 17)
+    d = torch.empty(2, 13, 17, 12, device=DEV)
+    check(lib.fu_op_nchw_to_nhwc(F32, ptr(x.to(DEV)), ptr(d), 2, 9, 13, 17, 12, stream()))
+    back = torch.empty(2, 9, 13, 17, device=DEV)
+    check(lib.fu_op_nhwc_to_nchw(F32, ptr(d), ptr(back), 2, 9, 13, 17, 12, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x)
+    assert float(d[..., 9:].abs().max()) == 0.0

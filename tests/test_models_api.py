@@ -1,0 +1,84 @@
+"""CPU: the plugin surface mirrors st_water_seg.models (registry, ctor, state_dict keys, error behaviour)."""
+import pytest
+import torch
+
+from floodplanet_code_amd.metrics import SegmentationMetrics
+from floodplanet_code_amd.models import MODELS, EarlyFusionModel, WaterSegmentationModel, build_model
+from floodplanet_code_amd.unet import HipUNet
+from oracle import unet_oracle as O
+
+
+def test_registry_names_and_positional_forwarding():
+    assert set(MODELS) == {"ms_model", "ef_model", "lf_model"}
+    m = build_model("ms_model", {"ms_image": 4}, 3, 1e-4, log_image_iter=50, to_rgb_fcn=None, ignore_index=0,
+                    optimizer_name="adam")
+    assert isinstance(m, WaterSegmentationModel) and m.lr == 1e-4 and m.ignore_index == 0
+    m = build_model("ef_model", {"ms_image": 8, "dem": 1}, 3, 1e-4, 50, None, -1)
+    assert isinstance(m, EarlyFusionModel) and m.ignore_index == 2  # -1 -> n_classes-1 (water_seg_model.py:35-36)
+    assert m.model.n_channels == 9
+
+
+def test_unknown_model_prints_then_unbound_local(capsys):
+    with pytest.raises(UnboundLocalError):
+        build_model("nope", {"a": 1}, 3, 1e-4, 50, None, 0)
+    assert "Could not find model named: nope" in capsys.readouterr().out
+
+
+def test_non_dict_in_channels_and_bad_optimizer():
+    with pytest.raises(UnboundLocalError):
+        WaterSegmentationModel(4, 3, 1e-4, ignore_index=0)
+    m = WaterSegmentationModel({"x": 4}, 3, 1e-4, ignore_index=0, optimizer_name="sgd")
+    with pytest.raises(NotImplementedError, match="sgd"):
+        m.configure_optimizers()
+    opt = WaterSegmentationModel({"x": 4}, 3, 1e-4, ignore_index=0).configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-4
+
+
+@pytest.mark.parametrize("n_in,base", [(8, 64), (4, 8), (12, 16)])
+def test_state_dict_keys_and_shapes_match_reference(n_in, base):
+    net = HipUNet(n_in, 3, bilinear=True, base_channels=base)
+    spec = O.param_spec(n_in, 3, base, True)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, (shape, _) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    m = WaterSegmentationModel({"img": n_in}, 3, 1e-4, ignore_index=0, base_channels=base)
+    assert list(m.state_dict().keys()) == ["model." + k for k in spec]
+
+
+def test_seeded_init_equals_torch_modules():
+    """Same construction order and init calls as nn.Conv2d/BatchNorm2d => same weights for one seed."""
+    torch.manual_seed(0)
+    net = HipUNet(4, 3, base_channels=8)
+    torch.manual_seed(0)
+    ref_first = torch.nn.Conv2d(4, 8, 3, padding=1)
+    assert torch.equal(net.inc.double_conv._modules["0"].weight, ref_first.weight)
+    assert torch.equal(net.inc.double_conv._modules["0"].bias, ref_first.bias)
+
+
+def test_load_state_dict_roundtrip_with_oracle_state():
+    st = O.make_state(4, 3, 8, True, seed=0)
+    net = HipUNet(4, 3, base_channels=8)
+    net.load_state_dict(st, strict=True)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, st[k]), k
+
+
+def test_no_cpu_fallback():
+    net = HipUNet(4, 3, base_channels=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 4, 32, 32))
+
+
+def test_metrics_formulas():
+    m = SegmentationMetrics(3, ignore_index=0, prefix="val_")
+    pred = torch.tensor([1, 1, 2, 0, 1, 2])
+    tgt = torch.tensor([1, 2, 2, 0, 0, 1])
+    out = m(pred, tgt)  # valid: targets 1,2,2,1 -> preds 1,1,2,2 -> tp=2, N=4
+    assert abs(out["val_MulticlassAccuracy"].item() - 0.5) < 1e-6
+    assert abs(out["val_MulticlassF1Score"].item() - 0.5) < 1e-6
+    assert abs(out["val_MulticlassJaccardIndex"].item() - 2 / 6) < 1e-6
+    conf = O.confusion_counts(pred, tgt, 3, 0)
+    assert torch.equal(m.confusion(), torch.from_numpy(conf))
+    ref = O.metrics_from_counts(conf)
+    assert abs(ref["MulticlassAccuracy"] - 0.5) < 1e-9

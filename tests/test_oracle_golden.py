@@ -1,0 +1,64 @@
+"""CPU: the oracle (oracle/unet_oracle.py) against the golden fixtures produced from the REAL reference by
+oracle/make_golden.py.  In the generating container the match is bit-exact; here a tight tolerance is used
+because another host CPU may pick other ATen/oneDNN code paths."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case_inputs, golden_names, is_dead_bias, load_golden
+from oracle import unet_oracle as O
+
+FAST = [n for n in golden_names() if n.startswith("s_")] + ["m_base8_64", "f_full_c8_32"]
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_oracle_matches_reference_fixture(name):
+    torch.set_num_threads(4)
+    meta, z = load_golden(name)
+    batch, st = case_inputs(meta)
+    ii, lr = meta["resolved_ignore_index"], meta["lr"]
+    ef = len(meta.get("extras", ())) > 0
+    opt = O.new_adam_state(st)
+    logits1, loss1, grads1 = O.train_step(st, opt, batch, ii, lr, meta["bilinear"], ef)
+    np.testing.assert_allclose(logits1.numpy(), z["logits1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(loss1.item(), z["loss1"].item(), rtol=1e-5, atol=1e-6)
+    names = meta["names"]
+    for j, k in enumerate(names):
+        if is_dead_bias(k):  # analytically zero: pure rounding noise, thread-count dependent
+            continue
+        g = grads1[k].double()
+        s = z["grad_stats1"][j]
+        assert abs(g.pow(2).sum().sqrt().item() - s[2]) <= 1e-4 * max(s[2], 1e-6) + 1e-7, k
+        if f"g1_{j}" in z.files:
+            ref = torch.from_numpy(z[f"g1_{j}"]).double()
+            assert (g - ref).norm() <= 1e-4 * ref.norm() + 1e-9, k
+    conf = O.confusion_counts(logits1.argmax(1), batch["target"], meta["n_classes"], ii)
+    assert conf.sum() == meta["n_valid"]
+    if np.abs(np.sort(z["logits1"], axis=1)[:, -1] - np.sort(z["logits1"], axis=1)[:, -2]).min() > 1e-4:
+        np.testing.assert_array_equal(conf, z["confusion1"])
+    logits2, loss2, _ = O.train_step(st, opt, batch, ii, lr, meta["bilinear"], ef)
+    np.testing.assert_allclose(loss2.item(), z["loss2"].item(), rtol=2e-4, atol=1e-6)
+    ev = O.eval_forward(st, batch, meta["bilinear"], ef)
+    np.testing.assert_allclose(ev.numpy(), z["eval_logits"], rtol=0, atol=2e-3)
+
+
+def test_all_ignored_gives_zero_loss_and_zero_grads():
+    meta, z = load_golden("s_all_ignored")
+    batch, st = case_inputs(meta)
+    _, loss, grads = O.loss_and_grads(st, batch, meta["resolved_ignore_index"])
+    assert loss.item() == 0.0 and z["loss1"].item() == 0.0
+    assert all(float(g.abs().max()) == 0.0 for g in grads.values())
+
+
+def test_algorithmic_flops_match_survey():
+    fwd, train = O.conv_flops_per_tile(8, 256, 256)
+    assert abs(fwd / 1e9 - 80.354) < 1e-3 and abs(train / 1e9 - 240.459) < 1e-3
+    fwd, train = O.conv_flops_per_tile(9, 512, 512)
+    assert abs(fwd / 1e9 - 321.720) < 1e-3 and abs(train / 1e9 - 962.442) < 1e-3
+
+
+def test_param_spec_counts():
+    spec = O.param_spec(8, 3)
+    n = sum(int(np.prod(s)) if len(s) else 1 for _, (s, kind) in spec.items() if O.is_trainable(kind))
+    assert n == 17270403 and len(spec) == 128
+    assert sum(1 for _, (_, kind) in spec.items() if O.is_trainable(kind)) == 74
