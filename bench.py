@@ -39,15 +39,28 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: cgroup quota if there is one, else the affinity mask, capped at
+    the GPU box's per-GPU CPU share (16) so that torch does not oversubscribe a 256-thread host."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("FU_BENCH_CPU_THREADS", "16")))
+
+
 def cpu_baseline(channels, size, cpu_batch, cpu_steps):
     """The oracle (kind 'port': torch-CPU restatement of the reference step, pinned bit-exactly against the
     reference in the dev container) on this box's host cores, bounded sample."""
     from oracle import unet_oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     st = O.make_state(channels, 3, 64, True, seed=0, nontrivial_bn=False)
     opt = O.new_adam_state(st)

@@ -68,7 +68,8 @@ def test_conv3x3_forward_and_stats(shape):
     y = torch.empty(B, H, W, Cout, device=DEV)
     ssum = torch.empty(Cout, device=DEV)
     ssq = torch.empty(Cout, device=DEV)
-    check(lib.fu_op_conv3x3_fwd(F32, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(w.to(DEV)), ptr(bias.to(DEV)),
+    dw_, dbias = w.to(DEV), bias.to(DEV)   # keep every device tensor alive across the call
+    check(lib.fu_op_conv3x3_fwd(F32, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(dw_), ptr(dbias),
                                 ptr(y), Cout, B, H, W, ptr(ssum), ptr(ssq), stream()))
     torch.cuda.synchronize()
     out = nchw(y)
@@ -88,8 +89,8 @@ def test_conv3x3_dgrad(shape):
     ref = torch.nn.grad.conv2d_input((B, C0 + C1, H, W), w, dy, padding=1)
     dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV)
     dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV) if C1 else None
-    check(lib.fu_op_conv3x3_dgrad(F32, ptr(nhwc(dy)), Cout, ptr(w.to(DEV)), ptr(dx0), C0, ptr(dx1), C1, B, H, W,
-                                  stream()))
+    ddy, dw_ = nhwc(dy), w.to(DEV)
+    check(lib.fu_op_conv3x3_dgrad(F32, ptr(ddy), Cout, ptr(dw_), ptr(dx0), C0, ptr(dx1), C1, B, H, W, stream()))
     torch.cuda.synchronize()
     got = nchw(dx0) if dx1 is None else torch.cat([nchw(dx0), nchw(dx1)], 1)
     assert rel_err(got, ref) < 1e-5
@@ -104,9 +105,10 @@ def test_conv3x3_wgrad(shape):
     dy = torch.randn(B, Cout, H, W, generator=g)
     ref = torch.nn.grad.conv2d_weight(xin, w.shape, dy, padding=1)
     dw = torch.full(w.shape, float("nan"), device=DEV)
-    check(lib.fu_op_conv3x3_wgrad(F32, ptr(nhwc(x0)), C0, ptr(a.to(DEV)) if bn else None,
-                                  ptr(b.to(DEV)) if bn else None, ptr(nhwc(x1)) if x1 is not None else None, C1,
-                                  ptr(nhwc(dy)), Cout, ptr(dw), B, H, W, stream()))
+    d0, d1, ddy = nhwc(x0), (nhwc(x1) if x1 is not None else None), nhwc(dy)
+    da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
+    check(lib.fu_op_conv3x3_wgrad(F32, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw), B, H, W,
+                                  stream()))
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), ref) < 1e-5
 
@@ -121,8 +123,9 @@ def test_maxpool(B, C, H, W, bn):
     z = torch.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if bn else x
     ref = F.max_pool2d(z, 2)
     out = torch.empty(B, H // 2, W // 2, C, device=DEV)
-    check(lib.fu_op_maxpool2(F32, ptr(nhwc(x)), ptr(a.to(DEV)) if bn else None, ptr(b.to(DEV)) if bn else None,
-                             ptr(out), B, H, W, C, stream()))
+    dx = nhwc(x)
+    da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
+    check(lib.fu_op_maxpool2(F32, ptr(dx), ptr(da), ptr(db), ptr(out), B, H, W, C, stream()))
     torch.cuda.synchronize()
     assert (nchw(out) - ref).abs().max().item() < 1e-6
 
@@ -137,7 +140,8 @@ def test_upsample_bilinear_align_corners_with_pad(B, C, H, W, oh, ow):
     dy, dx = oh - up.shape[2], ow - up.shape[3]
     ref = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
     out = torch.full((B, oh, ow, C), float("nan"), device=DEV)
-    check(lib.fu_op_upsample2(F32, ptr(nhwc(x)), None, None, ptr(out), B, H, W, C, oh, ow, stream()))
+    dxx = nhwc(x)
+    check(lib.fu_op_upsample2(F32, ptr(dxx), None, None, ptr(out), B, H, W, C, oh, ow, stream()))
     torch.cuda.synchronize()
     assert (nchw(out) - ref).abs().max().item() < 2e-6
 
@@ -146,7 +150,8 @@ def test_layout_roundtrip():
     lib = _lib.load()
     x = torch.randn(2, 9, 13, 17)
     d = torch.empty(2, 13, 17, 12, device=DEV)
-    check(lib.fu_op_nchw_to_nhwc(F32, ptr(x.to(DEV)), ptr(d), 2, 9, 13, 17, 12, stream()))
+    xd = x.to(DEV)
+    check(lib.fu_op_nchw_to_nhwc(F32, ptr(xd), ptr(d), 2, 9, 13, 17, 12, stream()))
     back = torch.empty(2, 9, 13, 17, device=DEV)
     check(lib.fu_op_nhwc_to_nchw(F32, ptr(d), ptr(back), 2, 9, 13, 17, 12, stream()))
     torch.cuda.synchronize()
