@@ -398,10 +398,18 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(WgP P) {
 }
 
 // dw[co][ci][tap] = sum_s slab[s][tap][ci][co]  (fixed order);  db[co] = sum_i dbp[i][co]
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cin, int Cout, int cin_real,
-                               float* __restrict__ dw, const float* __restrict__ dbp, int ndb, float* __restrict__ db) {
+// block = 64 consecutive outputs (co fastest -> coalesced slab reads) x 4 split lanes; each lane sums every 4th
+// split with 4 independent fp64 accumulators, lanes meet in LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cin, int Cout,
+                                                      int cin_real, float* __restrict__ dw,
+                                                      const float* __restrict__ dbp, int ndb, float* __restrict__ db) {
+  __shared__ double sm[4][64];
   const int64_t nW = (int64_t)9 * cin_real * Cout;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + o;
+  double acc = 0.0;
+  int64_t out_index = -1;
+  float* out_ptr = nullptr;
   if (idx < nW) {
     const int co = (int)(idx % Cout);
     const int64_t r = idx / Cout;
@@ -409,21 +417,33 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cin, i
     const int tap = (int)(r / cin_real);
     const int64_t sstride = (int64_t)9 * Cin * Cout;
     const float* p = slab + ((int64_t)tap * Cin + ci) * Cout + co;
-    double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += (double)p[s * sstride];
-    dw[((int64_t)co * cin_real + ci) * 9 + tap] = (float)acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = sl;
+    for (; s + 12 < S; s += 16) {
+      a0 += (double)p[(int64_t)s * sstride];
+      a1 += (double)p[(int64_t)(s + 4) * sstride];
+      a2 += (double)p[(int64_t)(s + 8) * sstride];
+      a3 += (double)p[(int64_t)(s + 12) * sstride];
+    }
+    for (; s < S; s += 4) a0 += (double)p[(int64_t)s * sstride];
+    acc = (a0 + a1) + (a2 + a3);
+    out_index = ((int64_t)co * cin_real + ci) * 9 + tap;
+    out_ptr = dw;
   } else if (db && idx < nW + Cout) {
     const int co = (int)(idx - nW);
-    double acc = 0.0;
-    for (int i = 0; i < ndb; ++i) acc += (double)dbp[(int64_t)i * Cout + co];
-    db[co] = (float)acc;
+    for (int i = sl; i < ndb; i += 4) acc += (double)dbp[(int64_t)i * Cout + co];
+    out_index = co;
+    out_ptr = db;
   }
+  sm[sl][o] = acc;
+  __syncthreads();
+  if (sl == 0 && out_ptr) out_ptr[out_index] = (float)((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
 }
 
 static inline void wgrad_split(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit) {
   const int np = B * ceil_div(H, WG_PTH) * ceil_div(W, WG_PTW);
   const int nT = ceil_div(Cin, WG_CT) * ceil_div(Cout, WG_CT);
-  int s = ceil_div(768, nT);
+  int s = ceil_div(512, nT);
   if (s > np) s = np;
   if (s < 1) s = 1;
   const int per = ceil_div(np, s);
@@ -455,7 +475,7 @@ int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float*
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   const int64_t nOut = (int64_t)9 * cin_real * Cout + (db ? Cout : 0);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nOut + 255) / 256)), dim3(256), 0, s, slab, P.S, P.Cin, Cout,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nOut + 63) / 64)), dim3(256), 0, s, slab, P.S, P.Cin, Cout,
                      cin_real, dw_oihw, db_partials, n_db_partials, db);
   FU_LAUNCH_CHECK();
   return 0;
