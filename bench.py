@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
+                    help="bf16 = BASELINE.json configs[1] (default); f32 = the 1e-4 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)

@@ -23,16 +23,15 @@ namespace fu {
 
 // ---- precision dispatch -------------------------------------------------------------------------
 int conv3x3_num_stat_tiles(Prec p, int B, int H, int W) {
-  (void)p;
-  return conv3x3_num_stat_tiles_f32(B, H, W);
+  return p == PREC_F32 ? conv3x3_num_stat_tiles_f32(B, H, W) : conv3x3_num_stat_tiles_bf16(B, H, W);
 }
 int launch_conv3x3(Prec p, const ConvIn& in, const void* wpk, const float* bias, void* dst0, int D0, void* dst1,
                    int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
   if (p == PREC_F32)
     return launch_conv3x3_f32(in, (const float*)wpk, bias, (float*)dst0, D0, (float*)dst1, D1, stats, n_stat_tiles, B,
                               H, W, s);
-  set_error("bf16 convolution kernels are not part of this build yet");
-  return FU_ERR_UNSUPPORTED;
+  return launch_conv3x3_bf16(in, (const bf16_t*)wpk, bias, (bf16_t*)dst0, D0, (bf16_t*)dst1, D1, stats, n_stat_tiles,
+                             B, H, W, s);
 }
 int64_t conv3x3_wgrad_slab_elems(Prec p, int Cin, int Cout, int B, int H, int W) {
   (void)p;
@@ -44,8 +43,8 @@ int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, flo
   if (p == PREC_F32)
     return launch_conv3x3_wgrad_f32(in, (const float*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
                                     db, B, H, W, s);
-  set_error("bf16 convolution kernels are not part of this build yet");
-  return FU_ERR_UNSUPPORTED;
+  return launch_conv3x3_wgrad_bf16(in, (const bf16_t*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
+                                   db, B, H, W, s);
 }
 int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout) {
   (void)p;
@@ -54,8 +53,7 @@ int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout) {
 int launch_pack_conv3x3(Prec p, const float* w_oihw, int Cout, int cin_real, int cin_pad, void* wfwd, void* wdgrad,
                         hipStream_t s) {
   if (p == PREC_F32) return launch_pack_conv3x3_f32(w_oihw, Cout, cin_real, cin_pad, (float*)wfwd, (float*)wdgrad, s);
-  set_error("bf16 convolution kernels are not part of this build yet");
-  return FU_ERR_UNSUPPORTED;
+  return launch_pack_conv3x3_bf16(w_oihw, Cout, cin_real, cin_pad, (bf16_t*)wfwd, (bf16_t*)wdgrad, s);
 }
 
 }  // namespace fu
@@ -558,10 +556,7 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
     set_error("bilinear=0 (ConvTranspose2d upsampling) is not implemented in this build");
     return FU_ERR_UNSUPPORTED;
   }
-  if (cfg->precision == FU_BF16) {
-    set_error("bf16 precision is not implemented in this build");
-    return FU_ERR_UNSUPPORTED;
-  }
+  FU_REQUIRE(cfg->precision == FU_F32 || b >= 8, "bf16 precision needs base_channels >= 8");
   FU_HIP_CHECK(hipSetDevice(cfg->device));
   fu_ctx* c = new (std::nothrow) fu_ctx();
   FU_REQUIRE(c, "out of host memory");

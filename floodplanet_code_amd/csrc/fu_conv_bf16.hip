@@ -1,0 +1,493 @@
+// bf16 3x3 convolutions for gfx950: im2col-free implicit GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//
+//   forward / dgrad : out[p][n] = sum_{tap,c} in[p+tap][c] * w[tap][n][c]
+//       workgroup tile = (WM*64) output pixels (TH x 16) x (WN*64) channels, K chunks of 32 input channels;
+//       each wave owns 64 px x 64 ch = 2x2 MFMA tiles (64 accumulator registers).  The halo tile of the virtual
+//       two-source NHWC input is staged once per chunk as [pixel][32ch + 8 pad] (80-byte rows: conflict-free
+//       ds_read_b128 fragments) with the producer's BatchNorm+ReLU applied on the way (fp32 math, one rounding to
+//       bf16); weights as [tap][n][32ch + 8 pad].  Next chunk's global loads are issued before the MFMA block.
+//       Epilogue: bias, bf16 NHWC stores (two destinations for dgrad), fp32 (sum, sumsq) partials per tile.
+//   wgrad : dW[tap][c][n] = sum_p in[p+tap][c] * dy[p][n]
+//       M = 64 c_in, N = 64 c_out, K = pixels.  Both operands need K (= pixels) contiguous per lane while memory is
+//       channel-contiguous: the tiles are staged untransposed ([pixel][64ch + 32 pad], 192-byte rows) and the
+//       fragments are fetched with the hardware transposing read ds_read_b64_tr_b16.  9 accumulator tiles per
+//       wave (one per tap); split-K slabs in fp32, reduced by the shared fixed-order kernel.
+#include "fu_common.h"
+
+namespace fu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define FU_LAUNCH_CHECK()                                                       \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) {                                                     \
+      set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 2;                                                                 \
+    }                                                                           \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (bf16): OIHW fp32 -> wf[tap][co][ci_pad] and wd[8-tap][ci_pad][co]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_bf16(const float* __restrict__ w, int Cout, int cin_real, int cin_pad,
+                            bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(idx % cin_pad);
+    const int64_t r = idx / cin_pad;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    const float v = ci < cin_real ? w[((int64_t)co * cin_real + ci) * 9 + tap] : 0.f;
+    const bf16_t h = f2bf(v);
+    if (wf) wf[idx] = h;                                                    // [tap][co][ci]
+    if (wd) wd[((int64_t)(8 - tap) * cin_pad + ci) * Cout + co] = h;        // [8-tap][ci][co]
+  }
+}
+
+int launch_pack_conv3x3_bf16(const float* w_oihw, int Cout, int cin_real, int cin_pad, bf16_t* wfwd, bf16_t* wdgrad,
+                             hipStream_t s) {
+  const int64_t total = (int64_t)9 * cin_pad * Cout;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_pack_bf16, dim3(g), dim3(256), 0, s, w_oihw, Cout, cin_real, cin_pad, wfwd, wdgrad, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad
+// ------------------------------------------------------------------------------------------------
+struct BConvP {
+  const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0;
+  const bf16_t* wpk;   // [9][N][Cin]
+  const float* bias;
+  bf16_t* dst0; bf16_t* dst1; float* stats;
+  int C0, C1, Cin, N, D0, D1, B, H, W, tilesX, tilesY, nPix, nCo;
+};
+
+template <int WM, int WN>
+struct BCfg {
+  static constexpr int TW = 16, TH = 4 * WM, BN = 64 * WN, KC = 32, KCP = 40;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int HWd = TW + 2, HHt = TH + 2, NHP = HHt * HWd;
+  static constexpr int A_UNITS = NHP * 4, W_UNITS = 9 * BN * 4;   // 16-byte units (8 channels)
+  static constexpr int A_ITERS = (A_UNITS + NT - 1) / NT, W_ITERS = (W_UNITS + NT - 1) / NT;
+  static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2;
+};
+
+__device__ __forceinline__ uint4 bn_relu_pack8(uint4 v, const float4& a0, const float4& a1, const float4& b0,
+                                               const float4& b1) {
+  float x[8];
+  x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+  x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+  x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
+  x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
+  x[0] = fmaxf(a0.x * x[0] + b0.x, 0.f); x[1] = fmaxf(a0.y * x[1] + b0.y, 0.f);
+  x[2] = fmaxf(a0.z * x[2] + b0.z, 0.f); x[3] = fmaxf(a0.w * x[3] + b0.w, 0.f);
+  x[4] = fmaxf(a1.x * x[4] + b1.x, 0.f); x[5] = fmaxf(a1.y * x[5] + b1.y, 0.f);
+  x[6] = fmaxf(a1.z * x[6] + b1.z, 0.f); x[7] = fmaxf(a1.w * x[7] + b1.w, 0.f);
+  uint4 o;
+  o.x = (unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16);
+  o.y = (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16);
+  o.z = (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16);
+  o.w = (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16);
+  return o;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
+  using Cfg = BCfg<WM, WN>;
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, KC = Cfg::KC, KCP = Cfg::KCP, NT = Cfg::NT;
+  constexpr int HWd = Cfg::HWd, NHP = Cfg::NHP, A_ITERS = Cfg::A_ITERS, W_ITERS = Cfg::W_ITERS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [NHP][KCP]
+  bf16_t* sW = sA + NHP * KCP;                        // [9][BN][KCP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int coT = logical / P.nPix;
+  const int pixT = logical - coT * P.nPix;
+  const int tx = pixT % P.tilesX;
+  const int t2 = pixT / P.tilesX;
+  const int ty = t2 % P.tilesY;
+  const int bb = t2 / P.tilesY;
+  const int x0 = tx * TW, y0 = ty * TH, n0 = coT * BN;
+
+  // ---- staging descriptors ---------------------------------------------------------------------
+  const int aq = tid & 3;  // channel octet inside the chunk (NT % 4 == 0)
+  int64_t a_pix[A_ITERS];
+  bool a_ok[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int u = tid + it * NT;
+    const int hp = u >> 2;
+    const int hy = hp / HWd, hx = hp - hy * HWd;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    a_ok[it] = (u < Cfg::A_UNITS) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    a_pix[it] = ((int64_t)bb * P.H + iy) * P.W + ix;
+  }
+  uint4 ra[A_ITERS];
+  uint4 rw[W_ITERS];
+  const bool has_bn = P.a0 != nullptr;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  auto load_chunk = [&](int k0) {
+    const int c = k0 + 8 * aq;
+    const bool from0 = c < P.C0;
+    float4 av0, av1, bv0, bv1;
+    if (has_bn && from0) {
+      av0 = *reinterpret_cast<const float4*>(P.a0 + c);
+      av1 = *reinterpret_cast<const float4*>(P.a0 + c + 4);
+      bv0 = *reinterpret_cast<const float4*>(P.b0 + c);
+      bv1 = *reinterpret_cast<const float4*>(P.b0 + c + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      uint4 v = zero4;
+      if (a_ok[it] && c < P.Cin) {
+        if (from0) {
+          v = *reinterpret_cast<const uint4*>(P.src0 + a_pix[it] * P.C0 + c);
+          if (has_bn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
+        } else {
+          v = *reinterpret_cast<const uint4*>(P.src1 + a_pix[it] * P.C1 + (c - P.C0));
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int u = tid + it * NT;
+      const int q = u & 3;
+      const int co = (u >> 2) % BN;
+      const int tap = u / (4 * BN);
+      const int n = n0 + co, ci = k0 + 8 * q;
+      rw[it] = (u < Cfg::W_UNITS && n < P.N && ci < P.Cin)
+                   ? *reinterpret_cast<const uint4*>(P.wpk + ((int64_t)tap * P.N + n) * P.Cin + ci)
+                   : zero4;
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      const int u = tid + it * NT;
+      if (u < Cfg::A_UNITS) *reinterpret_cast<uint4*>(sA + (u >> 2) * KCP + 8 * aq) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+      const int u = tid + it * NT;
+      if (u < Cfg::W_UNITS) *reinterpret_cast<uint4*>(sW + (u >> 2) * KCP + 8 * (u & 3)) = rw[it];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment base offsets (bf16 elements)
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+    aoff[mt] = (((wm * 2 + mt) * 2 + (l31 >> 4)) * HWd + (l31 & 15)) * KCP + 8 * lh;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) boff[nt] = (wn * 64 + nt * 32 + l31) * KCP + 8 * lh;
+
+  const int nChunks = (P.Cin + KC - 1) / KC;
+  load_chunk(0);
+  for (int ch = 0; ch < nChunks; ++ch) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * HWd + (tap % 3)) * KCP;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          af[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff + ks * 16);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          bfr[nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + wn * 64 + nt * 32 + l31;
+    const bool nok = n < P.N;
+    const float bias = (P.bias && nok) ? P.bias[n] : 0.f;
+    bf16_t* dst;
+    int dstride, dn;
+    if (n < P.D0) { dst = P.dst0; dstride = P.D0; dn = n; }
+    else { dst = P.dst1; dstride = P.D1; dn = n - P.D0; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = y0 + (wm * 2 + mt) * 2 + (p >> 4);
+        const int ox = x0 + (p & 15);
+        if (nok && oy < P.H && ox < P.W) {
+          const float v = acc[mt][nt][r];
+          ssum[nt] += v;
+          ssq[nt] += v * v;
+          dst[(((int64_t)bb * P.H + oy) * P.W + ox) * dstride + dn] = f2bf(v + bias);
+        }
+      }
+    }
+  }
+  if (P.stats) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [WM][BN][2]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      ssum[nt] += __shfl_xor(ssum[nt], 32, 64);
+      ssq[nt] += __shfl_xor(ssq[nt], 32, 64);
+    }
+    __syncthreads();
+    if (lh == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int cn = wn * 64 + nt * 32 + l31;
+        red[(wm * BN + cn) * 2 + 0] = ssum[nt];
+        red[(wm * BN + cn) * 2 + 1] = ssq[nt];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < P.N) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) { s += red[(m * BN + tid) * 2 + 0]; q += red[(m * BN + tid) * 2 + 1]; }
+      float* o = P.stats + ((int64_t)pixT * P.N + n0 + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+}
+
+int conv3x3_num_stat_tiles_bf16(int B, int H, int W) { return B * ceil_div(H, 8) * ceil_div(W, 16); }
+
+template <int WM, int WN>
+static int launch_cfg(BConvP& P, hipStream_t s) {
+  using Cfg = BCfg<WM, WN>;
+  P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
+  P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16<WM, WN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    attr_set = true;
+  }
+  const ProfSlot ps = g_prof_slot;
+  g_prof_slot = ProfSlot();
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL((k_conv3x3_bf16<WM, WN>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64, 1 = 256x128, 2 = 128x64
+
+int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
+                        int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
+  BConvP P;
+  P.src0 = (const bf16_t*)in.src0; P.src1 = (const bf16_t*)in.src1; P.a0 = in.a0; P.b0 = in.b0;
+  P.wpk = wpk; P.bias = bias; P.dst0 = dst0; P.dst1 = dst1; P.stats = stats;
+  P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.N = D0 + D1; P.D0 = D0; P.D1 = D1;
+  P.B = B; P.H = H; P.W = W;
+  FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
+             P.C0, P.C1);
+  // tile choice: prefer the 256x128 tile (highest FLOP per staged byte) when it still fills the chip,
+  // then 256x64, then 128x64 for the small deep levels
+  const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
+  const int64_t t128 = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
+  int cfg;
+  if (P.N >= 128 && t256 * ceil_div(P.N, 128) >= 256) cfg = 1;
+  else if (t256 * ceil_div(P.N, 64) >= 384) cfg = 0;
+  else cfg = 2;
+  if (g_bf16_force_cfg >= 0) cfg = g_bf16_force_cfg;
+  int st;
+  if (cfg == 1) st = launch_cfg<4, 2>(P, s);
+  else if (cfg == 0) st = launch_cfg<4, 1>(P, s);
+  else st = launch_cfg<2, 1>(P, s);
+  if (n_stat_tiles) *n_stat_tiles = P.nPix;
+  (void)t128;
+  return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------
+struct BWgP {
+  const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0; const bf16_t* dy;
+  float* slab;
+  int C0, C1, Cin, Cout, B, H, W, tilesX, tilesY, nPix, nCi, nCo, S, perSplit;
+};
+
+static constexpr int BW_PTH = 4, BW_PTW = 16, BW_HW = 18, BW_NHP = 6 * 18, BW_CT = 64;
+static constexpr int BW_RS = 96;  // row stride in bf16 elements: 64 channels + 32 pad = 192 bytes
+
+// Two transposing reads -> one MFMA fragment.  NOTE (hipcc / ROCm 7.2): the v4i16 form of the builtin followed by
+// per-element bit casts to __bf16 is miscompiled (element 0 is replicated); the v4bf16 form + shufflevector is correct
+// (checked on hardware, scratch/tr_probe3.hip).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+  const bf16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+  return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_bf16(BWgP P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sX = reinterpret_cast<bf16_t*>(smem_raw);   // [108][96]
+  bf16_t* sD = sX + BW_NHP * BW_RS;                   // [64][96]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int mi = wave >> 1, ni = wave & 1;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nT = P.nCi * P.nCo;
+  const int split = logical / nT;
+  const int t = logical - split * nT;
+  const int ciT = t / P.nCo, coT = t - ciT * P.nCo;
+  const int ci0 = ciT * BW_CT, co0 = coT * BW_CT;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  // transposing-read lane roles: group g = lane>>4 -> channel block 16*(g&1), pixel half g>>1 (= lh);
+  // within the group lane 4q+p supplies the address of pixel q, channels 4p..4p+3
+  const int g = lane >> 4, gi = lane & 15, tq = gi >> 2, tp = gi & 3;
+  const int tr_ch = 16 * (g & 1) + 4 * tp;
+  const int tr_px = 8 * lh + tq;   // column inside the 16-pixel row (second read: +4)
+
+  const bool has_bn = P.a0 != nullptr;
+  const int q8 = tid & 7;
+  const int cX = ci0 + 8 * q8;
+  const int cD = co0 + 8 * q8;
+  const bool from0 = cX < P.C0;
+  float4 av0, av1, bv0, bv1;
+  if (has_bn && from0 && cX < P.Cin) {
+    av0 = *reinterpret_cast<const float4*>(P.a0 + cX);
+    av1 = *reinterpret_cast<const float4*>(P.a0 + cX + 4);
+    bv0 = *reinterpret_cast<const float4*>(P.b0 + cX);
+    bv1 = *reinterpret_cast<const float4*>(P.b0 + cX + 4);
+  }
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  const int pt0 = split * P.perSplit;
+  const int pt1 = min(P.nPix, pt0 + P.perSplit);
+  for (int pt = pt0; pt < pt1; ++pt) {
+    const int tx = pt % P.tilesX;
+    const int t2 = pt / P.tilesX;
+    const int ty = t2 % P.tilesY;
+    const int bb = t2 / P.tilesY;
+    const int x0 = tx * BW_PTW, y0 = ty * BW_PTH;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {   // 108 pixels x 8 octets = 864 units
+      const int u = tid + it * 256;
+      const int hp = u >> 3;
+      if (hp < BW_NHP) {
+        const int hy = hp / BW_HW, hx = hp - hy * BW_HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        uint4 v = zero4;
+        if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W && cX < P.Cin) {
+          const int64_t pix = ((int64_t)bb * P.H + iy) * P.W + ix;
+          if (from0) {
+            v = *reinterpret_cast<const uint4*>(P.src0 + pix * P.C0 + cX);
+            if (has_bn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
+          } else {
+            v = *reinterpret_cast<const uint4*>(P.src1 + pix * P.C1 + (cX - P.C0));
+          }
+        }
+        *reinterpret_cast<uint4*>(sX + hp * BW_RS + 8 * q8) = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {   // 64 pixels x 8 octets
+      const int p = (tid + it * 256) >> 3;
+      const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+      uint4 v = zero4;
+      if (oy < P.H && ox < P.W && cD < P.Cout)
+        v = *reinterpret_cast<const uint4*>(P.dy + (((int64_t)bb * P.H + oy) * P.W + ox) * P.Cout + cD);
+      *reinterpret_cast<uint4*>(sD + p * BW_RS + 8 * q8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BW_PTH; ++r) {
+      const bf16_t* bd = sD + (r * 16 + tr_px) * BW_RS + ni * 32 + tr_ch;
+      const bf16x8 bfr = tr_frag(bd, bd + 4 * BW_RS);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16_t* ad = sX + ((r + tap / 3) * BW_HW + tr_px + tap % 3) * BW_RS + mi * 32 + tr_ch;
+        const bf16x8 afr = tr_frag(ad, ad + 4 * BW_RS);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  const int co = co0 + ni * 32 + l31;
+  if (co < P.Cout) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[tap][r];
+      }
+    }
+  }
+}
+
+void wgrad_split_shared(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit);
+int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
+                        int ndb, float* db, hipStream_t s);
+
+int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, float* slab, float* dw_oihw, int cin_real,
+                              const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
+                              hipStream_t s) {
+  BWgP P;
+  P.src0 = (const bf16_t*)in.src0; P.src1 = (const bf16_t*)in.src1; P.a0 = in.a0; P.b0 = in.b0; P.dy = dy;
+  P.slab = slab;
+  P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.Cout = Cout; P.B = B; P.H = H; P.W = W;
+  FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0 && Cout % 8 == 0, "wgrad_bf16: channel counts must be multiples of 8");
+  P.tilesX = ceil_div(W, BW_PTW); P.tilesY = ceil_div(H, BW_PTH);
+  wgrad_split_shared(P.Cin, Cout, B, H, W, &P.nPix, &P.S, &P.perSplit);
+  P.nCi = ceil_div(P.Cin, BW_CT); P.nCo = ceil_div(Cout, BW_CT);
+  const int grid = P.nCi * P.nCo * P.S;
+  const size_t sh = (size_t)(BW_NHP + 64) * BW_RS * sizeof(bf16_t);
+  const ProfSlot ps = g_prof_slot;
+  g_prof_slot = ProfSlot();
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL(k_wgrad_bf16, dim3(grid), dim3(256), sh, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
+}
+
+}  // namespace fu

@@ -440,7 +440,20 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   if (sl == 0 && out_ptr) out_ptr[out_index] = (float)((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
 }
 
+int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
+                        int ndb, float* db, hipStream_t s) {
+  const int64_t nOut = (int64_t)9 * cin_real * Cout + (db ? Cout : 0);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nOut + 63) / 64)), dim3(256), 0, s, slab, S, Cin, Cout,
+                     cin_real, dw, dbp, ndb, db);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+void wgrad_split_shared(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit);
 static inline void wgrad_split(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit) {
+  wgrad_split_shared(Cin, Cout, B, H, W, nPix, S, perSplit);
+}
+void wgrad_split_shared(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit) {
   const int np = B * ceil_div(H, WG_PTH) * ceil_div(W, WG_PTW);
   const int nT = ceil_div(Cin, WG_CT) * ceil_div(Cout, WG_CT);
   int s = ceil_div(512, nT);
@@ -474,11 +487,7 @@ int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float*
   hipLaunchKernelGGL(k_wgrad_f32, dim3(grid), dim3(256), sh, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
-  const int64_t nOut = (int64_t)9 * cin_real * Cout + (db ? Cout : 0);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nOut + 63) / 64)), dim3(256), 0, s, slab, P.S, P.Cin, Cout,
-                     cin_real, dw_oihw, db_partials, n_db_partials, db);
-  FU_LAUNCH_CHECK();
-  return 0;
+  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
 }
 
 }  // namespace fu

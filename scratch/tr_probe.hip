@@ -1,0 +1,22 @@
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__global__ void k(short* out) {
+  __shared__ short lds[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (short)i;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + threadIdx.x * 4));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+int main() {
+  short* d; hipMalloc(&d, 512); short h[256];
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+  hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
+  for (int l = 0; l < 64; ++l) {
+    printf("lane %2d:", l);
+    for (int j = 0; j < 4; ++j) printf("  (src lane %2d, elem %d)", h[l*4+j] / 4, h[l*4+j] % 4);
+    printf("\n");
+  }
+  return 0;
+}

@@ -157,3 +157,115 @@ def test_layout_roundtrip():
     torch.cuda.synchronize()
     assert torch.equal(back.cpu(), x)
     assert float(d[..., 9:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 kernels: operands are rounded to bf16 first, the fp32 torch result of those rounded operands is the
+# reference; the kernel's fp32 accumulator is rounded once to bf16 on store (relative error <= 2^-8).
+# ---------------------------------------------------------------------------------------------------
+BF16 = _lib.FU_BF16
+BF_SHAPES = [
+    # B, C0, C1, Cout, H, W, bn      (tile configuration hit)
+    (1, 64, 64, 64, 32, 32, True),   # 128x64 tiles
+    (2, 16, 8, 40, 9, 11, True),     # ragged, partial channel tile
+    (2, 8, 0, 64, 224, 224, False),  # 256x64 tiles, single ragged K chunk
+    (2, 32, 0, 128, 192, 192, True), # 256x128 tiles
+    (3, 32, 32, 136, 50, 38, True),  # odd sizes
+]
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc_bf(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def nchw_bf(x):
+    return x.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("shape", BF_SHAPES)
+def test_conv3x3_bf16_forward_and_stats(shape):
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, _ = make_conv_case(*shape)
+    x0r = bf(x0)
+    xin = bf(torch.relu(x0r * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))) if bn else x0r
+    if x1 is not None:
+        xin = torch.cat([xin, bf(x1)], 1)
+    ref = F.conv2d(xin, bf(w), None, padding=1)
+    d0, d1 = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None)
+    da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
+    dw_, dbias = w.to(DEV), bias.to(DEV)
+    y = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    ssum = torch.empty(Cout, device=DEV)
+    ssq = torch.empty(Cout, device=DEV)
+    check(lib.fu_op_conv3x3_fwd(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(dw_), ptr(dbias), ptr(y), Cout,
+                                B, H, W, ptr(ssum), ptr(ssq), stream()))
+    torch.cuda.synchronize()
+    out = nchw_bf(y)
+    full = ref + bias.view(1, -1, 1, 1)
+    assert (out - full).abs().max().item() <= 2.0 ** -7 * max(1.0, full.abs().max().item())
+    assert rel_err(out, full) < 4e-3
+    assert rel_err(ssq.cpu(), (ref * ref).sum((0, 2, 3))) < 1e-4
+    assert (ssum.cpu() - ref.sum((0, 2, 3))).abs().max() < 1e-3 * (ref.abs().sum((0, 2, 3)).max() + 1)
+
+
+@pytest.mark.parametrize("shape", BF_SHAPES)
+def test_conv3x3_bf16_dgrad(shape):
+    B, C0, C1, Cout, H, W, _ = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 3.0
+    ref = torch.nn.grad.conv2d_input((B, C0 + C1, H, W), bf(w), bf(dy), padding=1)
+    dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV, dtype=torch.bfloat16) if C1 else None
+    ddy, dw_ = nhwc_bf(dy), w.to(DEV)
+    check(lib.fu_op_conv3x3_dgrad(BF16, ptr(ddy), Cout, ptr(dw_), ptr(dx0), C0, ptr(dx1), C1, B, H, W, stream()))
+    torch.cuda.synchronize()
+    got = nchw_bf(dx0) if dx1 is None else torch.cat([nchw_bf(dx0), nchw_bf(dx1)], 1)
+    assert rel_err(got, ref) < 4e-3
+
+
+@pytest.mark.parametrize("shape", BF_SHAPES)
+def test_conv3x3_bf16_wgrad(shape):
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=2)
+    x0r = bf(x0)
+    xin = bf(torch.relu(x0r * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))) if bn else x0r
+    if x1 is not None:
+        xin = torch.cat([xin, bf(x1)], 1)
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(xin, w.shape, bf(dy), padding=1)
+    dw = torch.full(w.shape, float("nan"), device=DEV)
+    d0, d1, ddy = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None), nhwc_bf(dy)
+    da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
+    check(lib.fu_op_conv3x3_wgrad(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw), B, H, W,
+                                  stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), ref) < 1e-4   # exact products of bf16 operands, fp32 accumulation
+
+
+def test_bf16_memory_bound_ops():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 16, 20, 22, generator=g)
+    a = torch.rand(16, generator=g) + 0.5
+    b = torch.randn(16, generator=g) * 0.2
+    xr = bf(x)
+    z = torch.relu(xr * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    dx, da, db = nhwc_bf(x), a.to(DEV), b.to(DEV)
+    out = torch.empty(2, 10, 11, 16, device=DEV, dtype=torch.bfloat16)
+    check(lib.fu_op_maxpool2(BF16, ptr(dx), ptr(da), ptr(db), ptr(out), 2, 20, 22, 16, stream()))
+    up = torch.empty(2, 41, 45, 16, device=DEV, dtype=torch.bfloat16)
+    check(lib.fu_op_upsample2(BF16, ptr(dx), ptr(da), ptr(db), ptr(up), 2, 20, 22, 16, 41, 45, stream()))
+    torch.cuda.synchronize()
+    assert rel_err(nchw_bf(out), F.max_pool2d(z, 2)) < 3e-3
+    u = F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.pad(u, [0, 1, 0, 1])
+    assert rel_err(nchw_bf(up), ref) < 3e-3

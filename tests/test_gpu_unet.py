@@ -243,3 +243,63 @@ def test_full_size_properties():
     net.train()
     lz = net.train_step(x, torch.zeros_like(t), 0).item()
     assert lz == 0.0 and float(net.flat_grads().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 mode (bf16 activations / weights on the matrix cores, fp32 accumulation, statistics, loss, master weights).
+# Stated tolerance against the fp32 reference: the reference's own bf16-autocast run deviates from its fp32 run
+# by max 0.124 / rms 0.022 on the logits, so: logits max |d| <= 0.25, rms <= 0.05, loss |d| <= 0.03,
+# >= 93 % argmax agreement; training behaviour is checked by trajectory, not elementwise.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["m_base8_64", "f_full_c8_64_b2", "m_base16_300"])
+def test_bf16_step_within_stated_tolerance_of_fp32_reference(name):
+    meta, z = load_golden(name)
+    batch, st = case_inputs(meta)
+    ii = meta["resolved_ignore_index"]
+    net = HipUNet(meta["n_in"], 3, base_channels=meta["base"], precision="bf16")
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    loss, logits = net.loss(x, t, ii, return_logits=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    d = logits.detach().cpu().numpy() - z["logits1"]
+    assert np.abs(d).max() <= 0.25, np.abs(d).max()
+    assert np.sqrt((d ** 2).mean()) <= 0.05
+    assert abs(loss.item() - z["loss1"].item()) <= 0.03
+    agree = (logits.detach().cpu().numpy().argmax(1) == z["logits1"].argmax(1)).mean()
+    assert agree >= 0.93, agree
+    g = net.flat_grads()
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+    cos = []
+    for j, (k, p) in enumerate(net.named_parameters()):
+        if f"g1_{j}" in z.files and not is_dead_bias(k) and p.numel() >= 64:
+            a, b = p.grad.cpu().double().reshape(-1), torch.from_numpy(z[f"g1_{j}"]).double().reshape(-1)
+            cos.append((a @ b / (a.norm() * b.norm() + 1e-30)).item())
+    if cos:
+        assert np.median(cos) >= 0.9, np.median(cos)
+
+
+def test_bf16_training_trajectory_tracks_fp32():
+    st = O.make_state(8, 3, 16, True, seed=5, nontrivial_bn=False)
+    batch = O.make_batch(4, 8, 64, 64, seed=9)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    finals = {}
+    for prec in ("fp32", "bf16"):
+        net = HipUNet(8, 3, base_channels=16, precision=prec)
+        net.load_state_dict(st)
+        net.to(DEV).train()
+        losses = []
+        for step in range(1, 41):
+            losses.append(net.train_step(x, t, 0).item())
+            net.adam_step(1e-3, step)
+        net.eval()
+        with torch.no_grad():
+            pred = net(x).argmax(1)
+        valid = t != 0
+        finals[prec] = (losses, (pred[valid] == t[valid]).float().mean().item())
+    l32, a32 = finals["fp32"]
+    l16, a16 = finals["bf16"]
+    assert l32[-1] < 0.5 * l32[0] and l16[-1] < 0.5 * l16[0]
+    assert abs(l16[-1] - l32[-1]) <= 0.15 * l32[0]
+    assert abs(a16 - a32) <= 0.05
