@@ -14,11 +14,23 @@
 //       wave (one per tap); split-K slabs in fp32, reduced by the shared fixed-order kernel.
 #include "fu_common.h"
 
+#include <type_traits>
+
 namespace fu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: every array index below is a constant expression, so the staging registers are never
+// demoted to scratch (runtime-indexed private arrays are -- cdna guide rule 20)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 #define FU_LAUNCH_CHECK()                                                       \
   do {                                                                          \
@@ -68,14 +80,16 @@ struct BConvP {
   int C0, C1, Cin, N, D0, D1, B, H, W, tilesX, tilesY, nPix, nCo;
 };
 
-template <int WM, int WN>
+template <int WM, int WN, int NTW>
 struct BCfg {
-  static constexpr int TW = 16, TH = 4 * WM, BN = 64 * WN, KC = 32, KCP = 40;
+  // WM x WN waves; each wave owns 64 pixels x (32*NTW) channels
+  static constexpr int TW = 16, TH = 4 * WM, BN = 32 * NTW * WN, KC = 32, KCP = 40;
   static constexpr int NT = 64 * WM * WN;
   static constexpr int HWd = TW + 2, HHt = TH + 2, NHP = HHt * HWd;
   static constexpr int A_UNITS = NHP * 4, W_UNITS = 9 * BN * 4;   // 16-byte units (8 channels)
   static constexpr int A_ITERS = (A_UNITS + NT - 1) / NT, W_ITERS = (W_UNITS + NT - 1) / NT;
-  static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2;
+  static constexpr int AB_FLOATS = 2 * 1024;                      // BN scale/shift of source 0 (C0 <= 1024)
+  static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2 + AB_FLOATS * 4;
 };
 
 __device__ __forceinline__ uint4 bn_relu_pack8(uint4 v, const float4& a0, const float4& a1, const float4& b0,
@@ -97,14 +111,15 @@ __device__ __forceinline__ uint4 bn_relu_pack8(uint4 v, const float4& a0, const 
   return o;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int NTW>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
-  using Cfg = BCfg<WM, WN>;
+  using Cfg = BCfg<WM, WN, NTW>;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, KC = Cfg::KC, KCP = Cfg::KCP, NT = Cfg::NT;
   constexpr int HWd = Cfg::HWd, NHP = Cfg::NHP, A_ITERS = Cfg::A_ITERS, W_ITERS = Cfg::W_ITERS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [NHP][KCP]
   bf16_t* sW = sA + NHP * KCP;                        // [9][BN][KCP]
+  float* sAB = reinterpret_cast<float*>(sW + 9 * BN * KCP);  // [2][1024] BN scale / shift of source 0
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -119,122 +134,147 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
   const int bb = t2 / P.tilesY;
   const int x0 = tx * TW, y0 = ty * TH, n0 = coT * BN;
 
-  // ---- staging descriptors ---------------------------------------------------------------------
+  const bool has_bn = P.a0 != nullptr;
+  if (has_bn) {
+    for (int c = tid; c < P.C0; c += NT) { sAB[c] = P.a0[c]; sAB[1024 + c] = P.b0[c]; }
+  }
+
+  // ---- staging descriptors: loads are UNCONDITIONAL from clamped addresses (no branch, no early wait);
+  //      masking to zero happens when the registers are written to LDS -----------------------------------
   const int aq = tid & 3;  // channel octet inside the chunk (NT % 4 == 0)
-  int64_t a_pix[A_ITERS];
-  bool a_ok[A_ITERS];
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
+  int a_pix[A_ITERS];
+  unsigned a_okmask = 0;
+  static_for<0, A_ITERS>([&](auto I) {
+    constexpr int it = decltype(I)::value;
     const int u = tid + it * NT;
     const int hp = u >> 2;
     const int hy = hp / HWd, hx = hp - hy * HWd;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    a_ok[it] = (u < Cfg::A_UNITS) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-    a_pix[it] = ((int64_t)bb * P.H + iy) * P.W + ix;
-  }
+    const bool ok = (u < Cfg::A_UNITS) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+    a_okmask |= ok ? (1u << it) : 0u;
+    a_pix[it] = ok ? ((bb * P.H + iy) * P.W + ix) : 0;
+  });
+  int w_off[W_ITERS];
+  unsigned w_okmask = 0;
+  static_for<0, W_ITERS>([&](auto I) {
+    constexpr int it = decltype(I)::value;
+    const int u = tid + it * NT;
+    const int q = u & 3;
+    const int co = (u >> 2) % BN;
+    const int tap = u / (4 * BN);
+    const int n = n0 + co;
+    const bool ok = (u < Cfg::W_UNITS) && n < P.N;
+    w_okmask |= ok ? (1u << it) : 0u;
+    w_off[it] = ok ? ((tap * P.N + n) * P.Cin + 8 * q) : 0;
+  });
   uint4 ra[A_ITERS];
   uint4 rw[W_ITERS];
-  const bool has_bn = P.a0 != nullptr;
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
   auto load_chunk = [&](int k0) {
     const int c = k0 + 8 * aq;
+    const bool cval = c < P.Cin;
     const bool from0 = c < P.C0;
+    const bf16_t* base = (from0 || !cval) ? P.src0 : P.src1;
+    const int cs = (from0 || !cval) ? P.C0 : P.C1;
+    const int cc = !cval ? 0 : (from0 ? c : c - P.C0);
+    static_for<0, A_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      ra[it] = *reinterpret_cast<const uint4*>(base + (int64_t)a_pix[it] * cs + cc);
+    });
+    // weights: ci = k0 + 8q; the last chunk of a ragged Cin is clamped to offset 0 and masked at store time
+    static_for<0, W_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int q = (tid + it * NT) & 3;
+      const bool wv = k0 + 8 * q < P.Cin;
+      rw[it] = *reinterpret_cast<const uint4*>(P.wpk + (wv ? (int64_t)w_off[it] + k0 : 0));
+    });
+  };
+
+  auto store_chunk = [&](int k0) {
+    const int c = k0 + 8 * aq;
+    const bool cval = c < P.Cin;
+    const bool bn = has_bn && c < P.C0;
     float4 av0, av1, bv0, bv1;
-    if (has_bn && from0) {
-      av0 = *reinterpret_cast<const float4*>(P.a0 + c);
-      av1 = *reinterpret_cast<const float4*>(P.a0 + c + 4);
-      bv0 = *reinterpret_cast<const float4*>(P.b0 + c);
-      bv1 = *reinterpret_cast<const float4*>(P.b0 + c + 4);
+    if (bn) {
+      av0 = *reinterpret_cast<const float4*>(sAB + c);
+      av1 = *reinterpret_cast<const float4*>(sAB + c + 4);
+      bv0 = *reinterpret_cast<const float4*>(sAB + 1024 + c);
+      bv1 = *reinterpret_cast<const float4*>(sAB + 1024 + c + 4);
     }
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      uint4 v = zero4;
-      if (a_ok[it] && c < P.Cin) {
-        if (from0) {
-          v = *reinterpret_cast<const uint4*>(P.src0 + a_pix[it] * P.C0 + c);
-          if (has_bn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
-        } else {
-          v = *reinterpret_cast<const uint4*>(P.src1 + a_pix[it] * P.C1 + (c - P.C0));
-        }
+    static_for<0, A_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int u = tid + it * NT;
+      if (u < Cfg::A_UNITS) {
+        uint4 v = ra[it];
+        if (bn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
+        const bool keep = cval && ((a_okmask >> it) & 1u);   // component-wise: a ?: on uint4 lvalues would take
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u;         // addresses and demote the arrays to scratch
+        v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        *reinterpret_cast<uint4*>(sA + (u >> 2) * KCP + 8 * aq) = v;
       }
-      ra[it] = v;
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) {
+    });
+    static_for<0, W_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
       const int u = tid + it * NT;
-      const int q = u & 3;
-      const int co = (u >> 2) % BN;
-      const int tap = u / (4 * BN);
-      const int n = n0 + co, ci = k0 + 8 * q;
-      rw[it] = (u < Cfg::W_UNITS && n < P.N && ci < P.Cin)
-                   ? *reinterpret_cast<const uint4*>(P.wpk + ((int64_t)tap * P.N + n) * P.Cin + ci)
-                   : zero4;
-    }
+      if (u < Cfg::W_UNITS) {
+        const bool wv = (k0 + 8 * (u & 3) < P.Cin) && ((w_okmask >> it) & 1u);
+        uint4 v = rw[it];
+        v.x = wv ? v.x : 0u; v.y = wv ? v.y : 0u; v.z = wv ? v.z : 0u; v.w = wv ? v.w : 0u;
+        *reinterpret_cast<uint4*>(sW + (u >> 2) * KCP + 8 * (u & 3)) = v;
+      }
+    });
   };
 
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int u = tid + it * NT;
-      if (u < Cfg::A_UNITS) *reinterpret_cast<uint4*>(sA + (u >> 2) * KCP + 8 * aq) = ra[it];
-    }
-#pragma unroll
-    for (int it = 0; it < W_ITERS; ++it) {
-      const int u = tid + it * NT;
-      if (u < Cfg::W_UNITS) *reinterpret_cast<uint4*>(sW + (u >> 2) * KCP + 8 * (u & 3)) = rw[it];
-    }
-  };
-
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment base offsets (bf16 elements)
-  int aoff[2], boff[2];
+  int aoff[2], boff[NTW];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     aoff[mt] = (((wm * 2 + mt) * 2 + (l31 >> 4)) * HWd + (l31 & 15)) * KCP + 8 * lh;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) boff[nt] = (wn * 64 + nt * 32 + l31) * KCP + 8 * lh;
+  for (int nt = 0; nt < NTW; ++nt) boff[nt] = (wn * 32 * NTW + nt * 32 + l31) * KCP + 8 * lh;
 
   const int nChunks = (P.Cin + KC - 1) / KC;
   load_chunk(0);
   for (int ch = 0; ch < nChunks; ++ch) {
+    __syncthreads();            // previous chunk's fragment reads are done (and sAB is visible on the first pass)
+    store_chunk(ch * KC);
     __syncthreads();
-    store_chunk();
-    __syncthreads();
-    if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);
+    if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);   // raw loads stay in flight under the MFMA block
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * HWd + (tap % 3)) * KCP;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2], bfr[2];
+        bf16x8 af[2], bfr[NTW];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
           af[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff + ks * 16);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
           bfr[nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NTW; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
       }
     }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+  float ssum[NTW], ssq[NTW];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = n0 + wn * 64 + nt * 32 + l31;
+  for (int nt = 0; nt < NTW; ++nt) {
+    ssum[nt] = 0.f; ssq[nt] = 0.f;
+    const int n = n0 + wn * 32 * NTW + nt * 32 + l31;
     const bool nok = n < P.N;
     const float bias = (P.bias && nok) ? P.bias[n] : 0.f;
     bf16_t* dst;
@@ -260,15 +300,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
   if (P.stats) {
     float* red = reinterpret_cast<float*>(smem_raw);  // [WM][BN][2]
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
       ssum[nt] += __shfl_xor(ssum[nt], 32, 64);
       ssq[nt] += __shfl_xor(ssq[nt], 32, 64);
     }
     __syncthreads();
     if (lh == 0) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int cn = wn * 64 + nt * 32 + l31;
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int cn = wn * 32 * NTW + nt * 32 + l31;
         red[(wm * BN + cn) * 2 + 0] = ssum[nt];
         red[(wm * BN + cn) * 2 + 1] = ssq[nt];
       }
@@ -285,29 +325,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
   }
 }
 
-int conv3x3_num_stat_tiles_bf16(int B, int H, int W) { return B * ceil_div(H, 8) * ceil_div(W, 16); }
+int conv3x3_num_stat_tiles_bf16(int B, int H, int W) { return B * ceil_div(H, 16) * ceil_div(W, 16); }
 
-template <int WM, int WN>
+template <int WM, int WN, int NTW>
 static int launch_cfg(BConvP& P, hipStream_t s) {
-  using Cfg = BCfg<WM, WN>;
+  using Cfg = BCfg<WM, WN, NTW>;
   P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
   static bool attr_set = false;
   if (!attr_set) {
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16<WM, WN>),
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16<WM, WN, NTW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
   const ProfSlot ps = g_prof_slot;
   g_prof_slot = ProfSlot();
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL((k_conv3x3_bf16<WM, WN>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  hipLaunchKernelGGL((k_conv3x3_bf16<WM, WN, NTW>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;
 }
 
-int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64, 1 = 256x128, 2 = 128x64
+int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64, 1 = 256x128, 2 = 256x32
 
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
                         int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
@@ -318,21 +358,20 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.B = B; P.H = H; P.W = W;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
-  // tile choice: prefer the 256x128 tile (highest FLOP per staged byte) when it still fills the chip,
-  // then 256x64, then 128x64 for the small deep levels
+  FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);
+  // tile choice (all tiles are 16x16 = 256 output pixels): the widest channel tile that still gives the chip
+  // >= 256 workgroups; 256x128 has the most FLOP per staged byte, 256x32 keeps the tiny deep levels parallel
   const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
-  const int64_t t128 = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
   int cfg;
   if (P.N >= 128 && t256 * ceil_div(P.N, 128) >= 256) cfg = 1;
-  else if (t256 * ceil_div(P.N, 64) >= 384) cfg = 0;
+  else if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 256) cfg = 0;
   else cfg = 2;
   if (g_bf16_force_cfg >= 0) cfg = g_bf16_force_cfg;
   int st;
-  if (cfg == 1) st = launch_cfg<4, 2>(P, s);
-  else if (cfg == 0) st = launch_cfg<4, 1>(P, s);
-  else st = launch_cfg<2, 1>(P, s);
+  if (cfg == 1) st = launch_cfg<4, 2, 2>(P, s);
+  else if (cfg == 0) st = launch_cfg<4, 1, 2>(P, s);
+  else st = launch_cfg<4, 1, 1>(P, s);
   if (n_stat_tiles) *n_stat_tiles = P.nPix;
-  (void)t128;
   return st;
 }
 
