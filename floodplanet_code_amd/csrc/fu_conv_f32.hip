@@ -398,53 +398,130 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(WgP P) {
 }
 
 // dw[co][ci][tap] = sum_s slab[s][tap][ci][co]  (fixed order);  db[co] = sum_i dbp[i][co]
-// block = 64 consecutive outputs (co fastest -> coalesced slab reads) x 4 split lanes; each lane sums every 4th
-// split with 4 independent fp64 accumulators, lanes meet in LDS in a fixed order (deterministic).
+// Bandwidth kernel: 256 threads = SL split lanes x (256/SL) float4 columns; a block owns 4*256/SL consecutive slab
+// elements (co fastest -> coalesced rows); every lane keeps 4 independent float4 loads in flight; lanes meet in
+// LDS in a fixed order (deterministic), then the block scatters its elements to OIHW.
+template <int SL>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cin, int Cout,
                                                       int cin_real, float* __restrict__ dw,
                                                       const float* __restrict__ dbp, int ndb, float* __restrict__ db) {
-  __shared__ double sm[4][64];
-  const int64_t nW = (int64_t)9 * cin_real * Cout;
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + o;
-  double acc = 0.0;
-  int64_t out_index = -1;
-  float* out_ptr = nullptr;
-  if (idx < nW) {
-    const int co = (int)(idx % Cout);
-    const int64_t r = idx / Cout;
-    const int ci = (int)(r % cin_real);
-    const int tap = (int)(r / cin_real);
-    const int64_t sstride = (int64_t)9 * Cin * Cout;
-    const float* p = slab + ((int64_t)tap * Cin + ci) * Cout + co;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int s = sl;
-    for (; s + 12 < S; s += 16) {
-      a0 += (double)p[(int64_t)s * sstride];
-      a1 += (double)p[(int64_t)(s + 4) * sstride];
-      a2 += (double)p[(int64_t)(s + 8) * sstride];
-      a3 += (double)p[(int64_t)(s + 12) * sstride];
+  constexpr int COLS = 256 / SL, ELEMS = 4 * COLS;
+  __shared__ float sm[SL][ELEMS];
+  const int64_t nSlab = (int64_t)9 * Cin * Cout;          // elements of one slab ([tap][ci][co], Cout % 4 == 0)
+  const int64_t nBlocksW = (nSlab + ELEMS - 1) / ELEMS;
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  if ((int64_t)blockIdx.x < nBlocksW) {
+    const int64_t e0 = (int64_t)blockIdx.x * ELEMS + col * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (e0 < nSlab) {
+      const float* p = slab + e0;
+      int s = sl;
+      for (; s + 3 * SL < S; s += 4 * SL) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)s * nSlab);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + SL) * nSlab);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2 * SL) * nSlab);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3 * SL) * nSlab);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; s < S; s += SL) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)s * nSlab);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      }
     }
-    for (; s < S; s += 4) a0 += (double)p[(int64_t)s * sstride];
-    acc = (a0 + a1) + (a2 + a3);
-    out_index = ((int64_t)co * cin_real + ci) * 9 + tap;
-    out_ptr = dw;
-  } else if (db && idx < nW + Cout) {
-    const int co = (int)(idx - nW);
-    for (int i = sl; i < ndb; i += 4) acc += (double)dbp[(int64_t)i * Cout + co];
-    out_index = co;
-    out_ptr = db;
+    sm[sl][col * 4 + 0] = (a0.x + a1.x) + (a2.x + a3.x);
+    sm[sl][col * 4 + 1] = (a0.y + a1.y) + (a2.y + a3.y);
+    sm[sl][col * 4 + 2] = (a0.z + a1.z) + (a2.z + a3.z);
+    sm[sl][col * 4 + 3] = (a0.w + a1.w) + (a2.w + a3.w);
+    __syncthreads();
+    // the block's summed elements go back IN PLACE into slab 0 (only this block ever touches them), coalesced;
+    // k_wgrad_transpose then turns [tap][ci][co] into OIHW with full-line writes
+    if (threadIdx.x < COLS && e0 < nSlab) {
+      float4 o;
+      float* op = &o.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < SL; ++k) acc += (double)sm[k][col * 4 + j];
+        op[j] = (float)acc;
+      }
+      *reinterpret_cast<float4*>(const_cast<float*>(slab) + e0) = o;
+    }
+  } else if (db) {
+    // bias gradient: 256 threads = 16 channels x 16 partial lanes, 8 independent loads in flight per lane
+    // (one thread walking all ~2000 partials is a 100+ us latency chain that would set this kernel's duration)
+    __shared__ double smd[16][16];
+    const int64_t bblk = (int64_t)blockIdx.x - nBlocksW;
+    const int c16 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int co = (int)(bblk * 16 + c16);
+    double acc = 0.0;
+    if (co < Cout) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int i = pl;
+      for (; i + 7 * 16 < ndb; i += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += dbp[(int64_t)(i + u * 16) * Cout + co];
+      }
+      for (; i < ndb; i += 16) a[0] += dbp[(int64_t)i * Cout + co];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)a[u];
+    }
+    smd[pl][c16] = acc;
+    __syncthreads();
+    if (pl == 0 && co < Cout) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += smd[k][c16];
+      db[co] = (float)t;
+    }
   }
-  sm[sl][o] = acc;
+}
+
+// packed [tap][Cin][Cout] (slab 0 after the reduce) -> dw OIHW [Cout][cin_real][9].
+// block tile: 32 co x 8 ci x 9 taps through LDS: 128-byte reads along co, 288-byte writes along (ci, tap).
+__global__ __launch_bounds__(256) void k_wgrad_transpose(const float* __restrict__ packed, int Cin, int Cout,
+                                                         int cin_real, float* __restrict__ dw) {
+  __shared__ float t[72][33];
+  const int nCo = (Cout + 31) / 32;
+  const int co0 = (blockIdx.x % nCo) * 32, ci0 = (blockIdx.x / nCo) * 8;
+  for (int i = threadIdx.x; i < 72 * 32; i += 256) {
+    const int row = i >> 5, c = i & 31;          // row = tap*8 + ci_local
+    const int tap = row >> 3, ci = ci0 + (row & 7), co = co0 + c;
+    t[row][c] = (ci < Cin && co < Cout) ? packed[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
+  }
   __syncthreads();
-  if (sl == 0 && out_ptr) out_ptr[out_index] = (float)((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
+  for (int i = threadIdx.x; i < 32 * 72; i += 256) {
+    const int c = i / 72, j = i - c * 72;        // j = ci_local*9 + tap  (OIHW order inside the tile)
+    const int cil = j / 9, tap = j - cil * 9;
+    const int ci = ci0 + cil, co = co0 + c;
+    if (ci < cin_real && co < Cout) dw[((int64_t)co * cin_real + ci) * 9 + tap] = t[tap * 8 + cil][c];
+  }
+}
+
+template <int SL>
+static int launch_wgrad_reduce_sl(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw,
+                                  const float* dbp, int ndb, float* db, hipStream_t s) {
+  constexpr int ELEMS = 4 * (256 / SL);
+  const int64_t nSlab = (int64_t)9 * Cin * Cout;
+  const int64_t blocks = (nSlab + ELEMS - 1) / ELEMS + (db ? (Cout + 15) / 16 : 0);
+  hipLaunchKernelGGL(k_wgrad_reduce<SL>, dim3((unsigned)blocks), dim3(256), 0, s, slab, S, Cin, Cout, cin_real, dw,
+                     dbp, ndb, db);
+  FU_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
                         int ndb, float* db, hipStream_t s) {
-  const int64_t nOut = (int64_t)9 * cin_real * Cout + (db ? Cout : 0);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nOut + 63) / 64)), dim3(256), 0, s, slab, S, Cin, Cout,
-                     cin_real, dw, dbp, ndb, db);
+  int st;
+  if (S >= 64) st = launch_wgrad_reduce_sl<16>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
+  else if (S >= 16) st = launch_wgrad_reduce_sl<4>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
+  else st = launch_wgrad_reduce_sl<1>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
+  if (st) return st;
+  const int blocks = ceil_div(Cout, 32) * ceil_div(Cin, 8);
+  hipLaunchKernelGGL(k_wgrad_transpose, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw);
   FU_LAUNCH_CHECK();
   return 0;
 }
