@@ -61,6 +61,52 @@ int launch_pack_conv3x3(Prec p, const float* w_oihw, int Cout, int cin_real, int
 // ---- plan structures ------------------------------------------------------------------------------
 namespace {
 
+// one launch packs every conv layer: device table of layers, element ranges by prefix sum
+struct PackDesc {
+  int64_t start;      // first packed element of this layer in the global element numbering
+  int64_t w_off;      // offset of the OIHW weight in the flat parameter buffer
+  int cout, cin_real, cin_pad, pad_;
+  void* wf;
+  void* wd;
+};
+constexpr int MAX_PACK = 32;
+struct PackTable { PackDesc d[MAX_PACK]; int n; int64_t total; };
+
+template <typename T, bool BF16_LAYOUT>
+__global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tab.total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int l = 0;
+#pragma unroll 1
+    for (int k = 1; k < tab.n; ++k) l = idx >= tab.d[k].start ? k : l;
+    const PackDesc& D = tab.d[l];
+    const int64_t e = idx - D.start;
+    const float* w = params + D.w_off;
+    int co, ci, tap;
+    if (BF16_LAYOUT) {            // element order [tap][co][ci]
+      ci = (int)(e % D.cin_pad);
+      const int64_t r = e / D.cin_pad;
+      co = (int)(r % D.cout);
+      tap = (int)(r / D.cout);
+    } else {                      // element order [tap][ci][co]
+      co = (int)(e % D.cout);
+      const int64_t r = e / D.cout;
+      ci = (int)(r % D.cin_pad);
+      tap = (int)(r / D.cin_pad);
+    }
+    const float v = ci < D.cin_real ? w[((int64_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
+    T* wf = (T*)D.wf;
+    T* wd = (T*)D.wd;
+    if (BF16_LAYOUT) {
+      wf[e] = (T)f2bf(v);
+      if (wd) wd[((int64_t)(8 - tap) * D.cin_pad + ci) * D.cout + co] = (T)f2bf(v);
+    } else {
+      ElemIO<T>::store1(wf + e, v);
+      if (wd) ElemIO<T>::store1(wd + ((int64_t)(8 - tap) * D.cout + co) * D.cin_pad + ci, v);
+    }
+  }
+}
+
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
@@ -171,6 +217,7 @@ struct fu_ctx {
   float* adam_m = nullptr;
   float* adam_v = nullptr;
   Profiler prof;
+  PackTable pack_tab;
   // state
   int last_batch = 0;
   bool fwd_training = false;
@@ -380,11 +427,28 @@ inline float* P(fu_ctx* c, int idx) { return c->P + c->params[idx].off; }
 inline float* G(fu_ctx* c, int idx) { return c->G + c->params[idx].off; }
 
 int repack(fu_ctx* c, hipStream_t s) {
-  for (int i = 0; i < 9; ++i)
-    for (int j = 0; j < 2; ++j) {
-      Conv& v = c->blk[i].c[j];
-      FU_TRY(launch_pack_conv3x3(c->prec, P(c, v.p_w), v.cout, v.cin_real, v.cin_pad, v.wf, v.wd, s));
-    }
+  PackTable& t = c->pack_tab;
+  if (t.n == 0) {
+    int64_t start = 0;
+    for (int i = 0; i < 9; ++i)
+      for (int j = 0; j < 2; ++j) {
+        Conv& v = c->blk[i].c[j];
+        PackDesc& d = t.d[t.n++];
+        d.start = start;
+        d.w_off = c->params[v.p_w].off;
+        d.cout = v.cout; d.cin_real = v.cin_real; d.cin_pad = v.cin_pad; d.pad_ = 0;
+        d.wf = v.wf; d.wd = v.wd;
+        start += (int64_t)9 * v.cin_pad * v.cout;
+      }
+    t.total = start;
+  }
+  const int grid = 2048;
+  if (c->prec == PREC_F32)
+    hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t);
+  else
+    hipLaunchKernelGGL((k_pack_all<bf16_t, true>), dim3(grid), dim3(256), 0, s, c->P, t);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
   c->packed_dirty = false;
   return 0;
 }
@@ -607,6 +671,7 @@ int fu_bind_buffers(fu_ctx* c, float* params, float* grads, float* running_mean,
   FU_REQUIRE(c && params && running_mean && running_var && num_batches_tracked, "fu_bind_buffers: null buffer");
   c->P = params; c->G = grads; c->RM = running_mean; c->RV = running_var; c->NBT = num_batches_tracked;
   c->packed_dirty = true;
+  c->pack_tab.n = 0;
   return FU_OK;
 }
 int fu_params_changed(fu_ctx* c) {

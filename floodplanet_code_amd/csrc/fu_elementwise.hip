@@ -109,6 +109,7 @@ __global__ void k_partials_reduce(const float* __restrict__ part, double* __rest
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
   if (c < C) {
+#pragma unroll 4
     for (int t = t0 + j; t < t1; t += 8) {
       const float* q = part + ((int64_t)t * C + c) * NV;
 #pragma unroll
@@ -143,21 +144,31 @@ static int reduce_partials(const float* part, double* out, int nPart, int C, hip
   return 0;
 }
 
+// fixed-shape xor tree over the 32 lanes of a half wave (deterministic); every lane ends with the total
+__device__ __forceinline__ double half_wave_sum(double v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm forward statistics -> coefficients
 // ------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(const double* __restrict__ dpart, int G, int C, double count,
-                              const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean_o,
-                              float* __restrict__ invstd_o, float* __restrict__ a_o, float* __restrict__ b_o,
-                              float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double S = 0.0, Q = 0.0;
-  for (int g = 0; g < G; ++g) {
-    S += dpart[((int64_t)g * C + c) * 2 + 0];
-    Q += dpart[((int64_t)g * C + c) * 2 + 1];
-  }
+__global__ __launch_bounds__(256) void k_bn_finalize(
+    const double* __restrict__ dpart, int G, int C, double count, const float* __restrict__ conv_bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ a_o, float* __restrict__ b_o,
+    float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt) {
+  // 8 channels per block, 32 lanes per channel: lane g fetches group g's partial (one memory latency instead of a
+  // G-long dependent chain), then a fixed xor tree
+  const int g = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool ok = c < C && g < G;
+  double S = ok ? dpart[((int64_t)g * C + c) * 2 + 0] : 0.0;
+  double Q = ok ? dpart[((int64_t)g * C + c) * 2 + 1] : 0.0;
+  S = half_wave_sum(S);
+  Q = half_wave_sum(Q);
+  if (c >= C || g != 0) return;
   const double m0 = S / count;
   double var = Q / count - m0 * m0;
   if (var < 0.0) var = 0.0;
@@ -183,7 +194,7 @@ int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, 
                        hipStream_t s) {
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nTiles, C, s, &G));
-  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, s, dscratch, G, C, (double)count,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C, (double)count,
                      conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt);
   FU_LAUNCH_CHECK();
   return 0;
@@ -263,15 +274,17 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y
   }
 }
 
-__global__ void k_bn_bwd_finalize(const double* __restrict__ dpart, int G, int C, double count,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double S1 = 0.0, S2 = 0.0;
-  for (int g = 0; g < G; ++g) {
-    S1 += dpart[((int64_t)g * C + c) * 2 + 0];
-    S2 += dpart[((int64_t)g * C + c) * 2 + 1];
-  }
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ dpart, int G, int C,
+                                                         double count, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int g = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool ok = c < C && g < G;
+  double S1 = ok ? dpart[((int64_t)g * C + c) * 2 + 0] : 0.0;
+  double S2 = ok ? dpart[((int64_t)g * C + c) * 2 + 1] : 0.0;
+  S1 = half_wave_sum(S1);
+  S2 = half_wave_sum(S2);
+  if (c >= C || g != 0) return;
   if (dbeta) dbeta[c] = (float)S1;
   if (dgamma) dgamma[c] = (float)S2;
   coef[c * 2 + 0] = (float)(S1 / count);
@@ -352,7 +365,7 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   FU_LAUNCH_CHECK();
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 64)), dim3(64), 0, s, dscratch, G, C, (double)npix,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C, (double)npix,
                      dgamma, dbeta, coef);
   FU_LAUNCH_CHECK();
   const size_t sh2 = (size_t)rows * C * sizeof(float);
@@ -702,12 +715,26 @@ __global__ void k_ce_loss(const float* __restrict__ logits, const int64_t* __res
     if (hist[i]) atomicAdd(&conf_tmp[i], (unsigned long long)hist[i]);
 }
 
-__global__ void k_ce_finalize(const float* __restrict__ partials, int nblk, int ncls, float* __restrict__ loss_out,
-                              int64_t* __restrict__ n_valid_dev, unsigned long long* __restrict__ conf_tmp,
-                              int64_t* __restrict__ conf_accum, int64_t* __restrict__ n_valid_out) {
+__global__ __launch_bounds__(256) void k_ce_finalize(const float* __restrict__ partials, int nblk, int ncls,
+                                                     float* __restrict__ loss_out, int64_t* __restrict__ n_valid_dev,
+                                                     unsigned long long* __restrict__ conf_tmp,
+                                                     int64_t* __restrict__ conf_accum,
+                                                     int64_t* __restrict__ n_valid_out) {
+  __shared__ double sm[2][256];
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) { s += (double)partials[i * 2]; c += (double)partials[i * 2 + 1]; }
+  sm[0][threadIdx.x] = s;
+  sm[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {   // fixed tree: deterministic
+    if ((int)threadIdx.x < w) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + w];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double s = 0.0, c = 0.0;
-    for (int i = 0; i < nblk; ++i) { s += (double)partials[i * 2]; c += (double)partials[i * 2 + 1]; }
+    s = sm[0][0]; c = sm[1][0];
     // CrossEntropyLoss mean over non-ignored pixels; 0/0 = NaN -> nan_to_num -> 0  (water_seg_model.py:104-106)
     const float loss = c > 0.0 ? (float)(s / c) : 0.f;
     if (loss_out) *loss_out = loss;
@@ -727,7 +754,7 @@ int launch_ce_loss(const float* logits_nhwc, const int64_t* target, int ncls, in
   hipLaunchKernelGGL(k_ce_loss, dim3(nblk), dim3(CE_BLOCK), 0, s, logits_nhwc, target, ncls, ignore_index, npix,
                      partials, conf_tmp);
   FU_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ce_finalize, dim3(1), dim3(64), 0, s, partials, nblk, ncls, loss_out, n_valid_dev, conf_tmp,
+  hipLaunchKernelGGL(k_ce_finalize, dim3(1), dim3(256), 0, s, partials, nblk, ncls, loss_out, n_valid_dev, conf_tmp,
                      confusion_accum, n_valid_out);
   FU_LAUNCH_CHECK();
   return 0;
@@ -844,13 +871,19 @@ __global__ void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y
   }
 }
 
-__global__ void k_head_bwd_finalize(const float* __restrict__ partials, int nblk, int C, int ncls,
-                                    float* __restrict__ dw, float* __restrict__ db) {
+__global__ __launch_bounds__(256) void k_head_bwd_finalize(const float* __restrict__ partials, int nblk, int C,
+                                                           int ncls, float* __restrict__ dw, float* __restrict__ db) {
+  // 8 elements per block, 32 lanes per element; each lane sums every 32nd block partial, fixed xor tree at the end
   const int stride = ncls * C + ncls;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= stride) return;
+  const int g = threadIdx.x & 31;
+  const int e = blockIdx.x * 8 + (threadIdx.x >> 5);
   double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += (double)partials[(int64_t)i * stride + e];
+  if (e < stride) {
+#pragma unroll 4
+    for (int i = g; i < nblk; i += 32) s += (double)partials[(int64_t)i * stride + e];
+  }
+  s = half_wave_sum(s);
+  if (e >= stride || g != 0) return;
   if (e < ncls * C) dw[e] = (float)s;
   else db[e - ncls * C] = (float)s;
 }
@@ -873,7 +906,7 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
     hipLaunchKernelGGL(k_head_bwd<bf16_t>, dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const bf16_t*)y, a, b, w, C,
                        ncls, npix, (bf16_t*)g, partials);
   FU_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 64)), dim3(64), 0, s, partials, nblk, C, ncls, dw, db);
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 8)), dim3(256), 0, s, partials, nblk, C, ncls, dw, db);
   FU_LAUNCH_CHECK();
   return 0;
 }
