@@ -14,6 +14,7 @@
 //       wave (one per tap); split-K slabs in fp32, reduced by the shared fixed-order kernel.
 #include "fu_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace fu {
@@ -359,13 +360,17 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
   FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);
-  // tile choice (all tiles are 16x16 = 256 output pixels): the widest channel tile that still gives the chip
-  // >= 256 workgroups; 256x128 has the most FLOP per staged byte, 256x32 keeps the tiny deep levels parallel
+  // tile choice (all tiles are 16x16 = 256 output pixels).  Measured on MI355X (profiles/): two 4-wave workgroups
+  // per CU (256x64 tile, 80 KB LDS) overlap one group's LDS staging with the other's MFMA block and beat the
+  // 8-wave 256x128 tile (higher FLOP/byte but lock-step phases) on every layer that yields >= 512 workgroups;
+  // 256x32 keeps the small deep levels at >= 256 workgroups.
   const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
   int cfg;
-  if (P.N >= 128 && t256 * ceil_div(P.N, 128) >= 256) cfg = 1;
-  else if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 256) cfg = 0;
+  if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512) cfg = 0;
   else cfg = 2;
+  static int env_cfg = -2;
+  if (env_cfg == -2) { const char* e = getenv("FU_BF16_CFG"); env_cfg = e ? atoi(e) : -1; }
+  if (env_cfg >= 0 && !(env_cfg == 1 && P.N < 128)) cfg = env_cfg;
   if (g_bf16_force_cfg >= 0) cfg = g_bf16_force_cfg;
   int st;
   if (cfg == 1) st = launch_cfg<4, 2, 2>(P, s);
