@@ -271,30 +271,58 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
+  // The accumulator holds one channel per lane and 16 pixels in registers; a 2-byte store per value would make the
+  // epilogue store-issue bound.  Two DPP exchanges inside each lane quad (xor 1, then xor 2) transpose 4 pixels x
+  // 4 channels so that every lane owns 4 consecutive channels of ONE pixel: one 8-byte store per 4 registers,
+  // each wave instruction writing 8 pixels x 64 contiguous bytes.
   float ssum[NTW], ssq[NTW];
+  const int qj = l31 & 3;
+  const bool q_even = !(l31 & 1), q_lo = qj < 2;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     ssum[nt] = 0.f; ssq[nt] = 0.f;
     const int n = n0 + wn * 32 * NTW + nt * 32 + l31;
     const bool nok = n < P.N;
     const float bias = (P.bias && nok) ? P.bias[n] : 0.f;
+    const int nq = n & ~3;                       // first channel of this lane quad (N, D0 are multiples of 8)
     bf16_t* dst;
     int dstride, dn;
-    if (n < P.D0) { dst = P.dst0; dstride = P.D0; dn = n; }
-    else { dst = P.dst1; dstride = P.D1; dn = n - P.D0; }
+    if (nq < P.D0) { dst = P.dst0; dstride = P.D0; dn = nq; }
+    else { dst = P.dst1; dstride = P.D1; dn = nq - P.D0; }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = acc[mt][nt][4 * g + k];
+          const int p = k + 8 * g + 4 * lh;
+          const int oy = y0 + (wm * 2 + mt) * 2 + (p >> 4);
+          const int ox = x0 + (p & 15);
+          if (nok && oy < P.H && ox < P.W) { ssum[nt] += a; ssq[nt] += a * a; }
+          v[k] = a + bias;
+        }
+        // level 1: pairs of channels
+        const float s01 = q_even ? v[1] : v[0];
+        const float s23 = q_even ? v[3] : v[2];
+        const float r01 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s01), 0xB1, 0xF, 0xF, true));
+        const float r23 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s23), 0xB1, 0xF, 0xF, true));
+        const unsigned A = q_even ? ((unsigned)f2bf(v[0]) | ((unsigned)f2bf(r01) << 16))
+                                  : ((unsigned)f2bf(r01) | ((unsigned)f2bf(v[1]) << 16));
+        const unsigned Bq = q_even ? ((unsigned)f2bf(v[2]) | ((unsigned)f2bf(r23) << 16))
+                                   : ((unsigned)f2bf(r23) | ((unsigned)f2bf(v[3]) << 16));
+        // level 2: pairs of channel pairs
+        const unsigned send = q_lo ? Bq : A;
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);
+        uint2 o;
+        o.x = q_lo ? A : recv;
+        o.y = q_lo ? recv : Bq;
+        const int p = qj + 8 * g + 4 * lh;       // this lane now owns pixel row qj of the register quad
         const int oy = y0 + (wm * 2 + mt) * 2 + (p >> 4);
         const int ox = x0 + (p & 15);
-        if (nok && oy < P.H && ox < P.W) {
-          const float v = acc[mt][nt][r];
-          ssum[nt] += v;
-          ssq[nt] += v * v;
-          dst[(((int64_t)bb * P.H + oy) * P.W + ox) * dstride + dn] = f2bf(v + bias);
-        }
+        if (nq < P.N && oy < P.H && ox < P.W)
+          *reinterpret_cast<uint2*>(dst + (((int64_t)bb * P.H + oy) * P.W + ox) * dstride + dn) = o;
       }
     }
   }
