@@ -34,8 +34,8 @@ int launch_conv3x3(Prec p, const ConvIn& in, const void* wpk, const float* bias,
                              B, H, W, s);
 }
 int64_t conv3x3_wgrad_slab_elems(Prec p, int Cin, int Cout, int B, int H, int W) {
-  (void)p;
-  return conv3x3_wgrad_slab_elems_f32(Cin, Cout, B, H, W);
+  return p == PREC_F32 ? conv3x3_wgrad_slab_elems_f32(Cin, Cout, B, H, W)
+                       : conv3x3_wgrad_slab_elems_bf16(Cin, Cout, B, H, W);
 }
 int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, float* slab, float* dw_oihw,
                          int cin_real, const float* db_partials, int n_db_partials, float* db, int B, int H, int W,

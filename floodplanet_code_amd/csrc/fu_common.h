@@ -141,6 +141,7 @@ int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float*
 int launch_pack_conv3x3_f32(const float* w_oihw, int Cout, int cin_real, int cin_pad, float* wfwd, float* wdgrad,
                             hipStream_t s);
 int conv3x3_num_stat_tiles_bf16(int B, int H, int W);
+int64_t conv3x3_wgrad_slab_elems_bf16(int Cin, int Cout, int B, int H, int W);
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
                         int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s);
 int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, float* slab, float* dw_oihw, int cin_real,

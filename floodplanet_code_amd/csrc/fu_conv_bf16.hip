@@ -417,9 +417,6 @@ struct BWgP {
   int C0, C1, Cin, Cout, B, H, W, tilesX, tilesY, nPix, nCi, nCo, S, perSplit;
 };
 
-static constexpr int BW_PTH = 4, BW_PTW = 16, BW_HW = 18, BW_NHP = 6 * 18, BW_CT = 64;
-static constexpr int BW_RS = 96;  // row stride in bf16 elements: 64 channels + 32 pad = 192 bytes
-
 // Two transposing reads -> one MFMA fragment.  NOTE (hipcc / ROCm 7.2): the v4i16 form of the builtin followed by
 // per-element bit casts to __bf16 is miscompiled (element 0 is replicated); the v4bf16 form + shufflevector is correct
 // (checked on hardware, scratch/tr_probe3.hip).
@@ -431,10 +428,28 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
   return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_bf16(BWgP P) {
+// WMI waves along c_in (32 each) x 2 waves along c_out (32 each); pixel stage = PTH x 16 pixels with halo.
+template <int WMI, int PTH>
+struct WCfg {
+  static constexpr int CI_T = 32 * WMI, CO_T = 64, NT = 128 * WMI, PTW = 16;
+  static constexpr int HWd = PTW + 2, NHP = (PTH + 2) * HWd, NPX = PTH * PTW;
+  static constexpr int RSX = CI_T + 32, RSD = CO_T + 32;    // row strides (elements): 64-byte residue mod 256 B
+  static constexpr int XQ = CI_T / 8, DQ = CO_T / 8;        // 16-byte units per pixel row
+  static constexpr int X_UNITS = NHP * XQ, D_UNITS = NPX * DQ;
+  static constexpr int X_ITERS = (X_UNITS + NT - 1) / NT, D_ITERS = (D_UNITS + NT - 1) / NT;
+  static constexpr int SMEM_BYTES = (NHP * RSX + NPX * RSD) * 2 + 2 * CI_T * 4;
+};
+
+template <int WMI, int PTH>
+__global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
+  using Cfg = WCfg<WMI, PTH>;
+  constexpr int CI_T = Cfg::CI_T, CO_T = Cfg::CO_T, NT = Cfg::NT, HWd = Cfg::HWd, NHP = Cfg::NHP, NPX = Cfg::NPX;
+  constexpr int RSX = Cfg::RSX, RSD = Cfg::RSD, XQ = Cfg::XQ, DQ = Cfg::DQ;
+  constexpr int X_ITERS = Cfg::X_ITERS, D_ITERS = Cfg::D_ITERS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* sX = reinterpret_cast<bf16_t*>(smem_raw);   // [108][96]
-  bf16_t* sD = sX + BW_NHP * BW_RS;                   // [64][96]
+  bf16_t* sX = reinterpret_cast<bf16_t*>(smem_raw);   // [NHP][RSX]
+  bf16_t* sD = sX + NHP * RSX;                        // [NPX][RSD]
+  float* sAB = reinterpret_cast<float*>(sD + NPX * RSD);  // [2][CI_T] BN scale / shift of this c_in tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int mi = wave >> 1, ni = wave & 1;
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(BWgP P) {
   const int split = logical / nT;
   const int t = logical - split * nT;
   const int ciT = t / P.nCo, coT = t - ciT * P.nCo;
-  const int ci0 = ciT * BW_CT, co0 = coT * BW_CT;
+  const int ci0 = ciT * CI_T, co0 = coT * CO_T;
 
   f32x16 acc[9];
 #pragma unroll
@@ -459,66 +474,105 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(BWgP P) {
   const int tr_px = 8 * lh + tq;   // column inside the 16-pixel row (second read: +4)
 
   const bool has_bn = P.a0 != nullptr;
-  const int q8 = tid & 7;
-  const int cX = ci0 + 8 * q8;
-  const int cD = co0 + 8 * q8;
-  const bool from0 = cX < P.C0;
-  float4 av0, av1, bv0, bv1;
-  if (has_bn && from0 && cX < P.Cin) {
-    av0 = *reinterpret_cast<const float4*>(P.a0 + cX);
-    av1 = *reinterpret_cast<const float4*>(P.a0 + cX + 4);
-    bv0 = *reinterpret_cast<const float4*>(P.b0 + cX);
-    bv1 = *reinterpret_cast<const float4*>(P.b0 + cX + 4);
+  if (has_bn) {
+    for (int c = tid; c < CI_T; c += NT) {
+      const int cc = ci0 + c;
+      const bool ok = cc < P.C0;
+      sAB[c] = ok ? P.a0[cc] : 1.f;
+      sAB[CI_T + c] = ok ? P.b0[cc] : 0.f;
+    }
   }
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  // this thread's channel octets (NT % XQ == 0 and NT % DQ == 0)
+  const int xq = tid % XQ, dq = tid % DQ;
+  const int cX = ci0 + 8 * xq;
+  const int cD = co0 + 8 * dq;
+  const bool xval = cX < P.Cin, dval = cD < P.Cout;
+  const bool from0 = cX < P.C0;
+  const bool xbn = has_bn && from0 && xval;
+  const bf16_t* xbase = (from0 || !xval) ? P.src0 : P.src1;
+  const int xcs = (from0 || !xval) ? P.C0 : P.C1;
+  const int xcc = !xval ? 0 : (from0 ? cX : cX - P.C0);
+  const int dcc = dval ? cD : 0;
+
+  uint4 rx[X_ITERS], rd[D_ITERS];
+  unsigned xmask = 0, dmask = 0;
+
+  auto load_tile = [&](int pt) {
+    const int tx = pt % P.tilesX;
+    const int t2 = pt / P.tilesX;
+    const int bb = t2 / P.tilesY;
+    const int y0 = (t2 % P.tilesY) * PTH;
+    const int x0 = tx * Cfg::PTW;
+    xmask = 0; dmask = 0;
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int u = tid + it * NT;
+      const int hp = u / XQ;
+      const int hy = hp / HWd, hx = hp - hy * HWd;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (u < Cfg::X_UNITS) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      xmask |= ok ? (1u << it) : 0u;
+      const int pix = ok ? ((bb * P.H + iy) * P.W + ix) : 0;
+      rx[it] = *reinterpret_cast<const uint4*>(xbase + (int64_t)pix * xcs + xcc);
+    });
+    static_for<0, D_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int u = tid + it * NT;
+      const int p = u / DQ;
+      const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+      const bool ok = (u < Cfg::D_UNITS) && oy < P.H && ox < P.W;
+      dmask |= ok ? (1u << it) : 0u;
+      const int pix = ok ? ((bb * P.H + oy) * P.W + ox) : 0;
+      rd[it] = *reinterpret_cast<const uint4*>(P.dy + (int64_t)pix * P.Cout + dcc);
+    });
+  };
+  auto store_tile = [&]() {
+    float4 av0, av1, bv0, bv1;
+    if (xbn) {
+      av0 = *reinterpret_cast<const float4*>(sAB + 8 * xq);
+      av1 = *reinterpret_cast<const float4*>(sAB + 8 * xq + 4);
+      bv0 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq);
+      bv1 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq + 4);
+    }
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int u = tid + it * NT;
+      if (u < Cfg::X_UNITS) {
+        uint4 v = rx[it];
+        if (xbn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
+        const bool keep = xval && ((xmask >> it) & 1u);
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        *reinterpret_cast<uint4*>(sX + (u / XQ) * RSX + 8 * xq) = v;
+      }
+    });
+    static_for<0, D_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int u = tid + it * NT;
+      if (u < Cfg::D_UNITS) {
+        uint4 v = rd[it];
+        const bool keep = dval && ((dmask >> it) & 1u);
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        *reinterpret_cast<uint4*>(sD + (u / DQ) * RSD + 8 * dq) = v;
+      }
+    });
+  };
 
   const int pt0 = split * P.perSplit;
   const int pt1 = min(P.nPix, pt0 + P.perSplit);
+  if (pt0 < pt1) load_tile(pt0);
   for (int pt = pt0; pt < pt1; ++pt) {
-    const int tx = pt % P.tilesX;
-    const int t2 = pt / P.tilesX;
-    const int ty = t2 % P.tilesY;
-    const int bb = t2 / P.tilesY;
-    const int x0 = tx * BW_PTW, y0 = ty * BW_PTH;
+    __syncthreads();            // previous stage's fragment reads are done (sAB visible on the first pass)
+    store_tile();
     __syncthreads();
+    if (pt + 1 < pt1) load_tile(pt + 1);   // in flight under the MFMA block
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {   // 108 pixels x 8 octets = 864 units
-      const int u = tid + it * 256;
-      const int hp = u >> 3;
-      if (hp < BW_NHP) {
-        const int hy = hp / BW_HW, hx = hp - hy * BW_HW;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        uint4 v = zero4;
-        if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W && cX < P.Cin) {
-          const int64_t pix = ((int64_t)bb * P.H + iy) * P.W + ix;
-          if (from0) {
-            v = *reinterpret_cast<const uint4*>(P.src0 + pix * P.C0 + cX);
-            if (has_bn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
-          } else {
-            v = *reinterpret_cast<const uint4*>(P.src1 + pix * P.C1 + (cX - P.C0));
-          }
-        }
-        *reinterpret_cast<uint4*>(sX + hp * BW_RS + 8 * q8) = v;
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {   // 64 pixels x 8 octets
-      const int p = (tid + it * 256) >> 3;
-      const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
-      uint4 v = zero4;
-      if (oy < P.H && ox < P.W && cD < P.Cout)
-        v = *reinterpret_cast<const uint4*>(P.dy + (((int64_t)bb * P.H + oy) * P.W + ox) * P.Cout + cD);
-      *reinterpret_cast<uint4*>(sD + p * BW_RS + 8 * q8) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < BW_PTH; ++r) {
-      const bf16_t* bd = sD + (r * 16 + tr_px) * BW_RS + ni * 32 + tr_ch;
-      const bf16x8 bfr = tr_frag(bd, bd + 4 * BW_RS);
+    for (int r = 0; r < PTH; ++r) {
+      const bf16_t* bd = sD + (r * 16 + tr_px) * RSD + ni * 32 + tr_ch;
+      const bf16x8 bfr = tr_frag(bd, bd + 4 * RSD);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const bf16_t* ad = sX + ((r + tap / 3) * BW_HW + tr_px + tap % 3) * BW_RS + mi * 32 + tr_ch;
-        const bf16x8 afr = tr_frag(ad, ad + 4 * BW_RS);
+        const bf16_t* ad = sX + ((r + tap / 3) * HWd + tr_px + tap % 3) * RSX + mi * 32 + tr_ch;
+        const bf16x8 afr = tr_frag(ad, ad + 4 * RSX);
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
       }
     }
@@ -536,9 +590,47 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(BWgP P) {
   }
 }
 
-void wgrad_split_shared(int Cin, int Cout, int B, int H, int W, int* nPix, int* S, int* perSplit);
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
                         int ndb, float* db, hipStream_t s);
+
+template <int WMI, int PTH>
+static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
+  using Cfg = WCfg<WMI, PTH>;
+  P.tilesX = ceil_div(P.W, Cfg::PTW); P.tilesY = ceil_div(P.H, PTH);
+  P.nPix = P.B * P.tilesX * P.tilesY;
+  P.nCi = ceil_div(P.Cin, Cfg::CI_T); P.nCo = ceil_div(P.Cout, Cfg::CO_T);
+  const int nT = P.nCi * P.nCo;
+  int S = ceil_div(target_wgs, nT);
+  if (S > P.nPix) S = P.nPix;
+  if (S < 1) S = 1;
+  P.perSplit = ceil_div(P.nPix, S);
+  P.S = ceil_div(P.nPix, P.perSplit);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16<WMI, PTH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    attr_set = true;
+  }
+  const ProfSlot ps = g_prof_slot;
+  g_prof_slot = ProfSlot();
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL((k_wgrad_bf16<WMI, PTH>), dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// upper bound of the slab size over the two configurations below
+int64_t conv3x3_wgrad_slab_elems_bf16(int Cin, int Cout, int B, int H, int W) {
+  const int64_t npix = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
+  const int nT128 = ceil_div(Cin, 128) * ceil_div(Cout, 64);
+  const int nT64 = ceil_div(Cin, 64) * ceil_div(Cout, 64);
+  int64_t s128 = ceil_div(256, nT128), s64 = ceil_div(512, nT64);
+  if (s128 > npix) s128 = npix;
+  if (s64 > npix) s64 = npix;
+  const int64_t smax = s128 > s64 ? s128 : s64;
+  return (smax + 1) * 9 * (int64_t)Cin * Cout;
+}
 
 int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, float* slab, float* dw_oihw, int cin_real,
                               const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
@@ -548,17 +640,10 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   P.slab = slab;
   P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.Cout = Cout; P.B = B; P.H = H; P.W = W;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0 && Cout % 8 == 0, "wgrad_bf16: channel counts must be multiples of 8");
-  P.tilesX = ceil_div(W, BW_PTW); P.tilesY = ceil_div(H, BW_PTH);
-  wgrad_split_shared(P.Cin, Cout, B, H, W, &P.nPix, &P.S, &P.perSplit);
-  P.nCi = ceil_div(P.Cin, BW_CT); P.nCo = ceil_div(Cout, BW_CT);
-  const int grid = P.nCi * P.nCo * P.S;
-  const size_t sh = (size_t)(BW_NHP + 64) * BW_RS * sizeof(bf16_t);
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
-  if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL(k_wgrad_bf16, dim3(grid), dim3(256), sh, s, P);
-  if (ps.stop) (void)hipEventRecord(ps.stop, s);
-  FU_LAUNCH_CHECK();
+  int st;
+  if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU
+  if (st) return st;
   return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
 }
 
