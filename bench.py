@@ -89,13 +89,18 @@ def main():
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(1, n_dev))  # (ranks share a device only in the gloo rehearsal)
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("FU_DIST_BACKEND", "nccl")   # "gloo" = rehearsal of the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from floodplanet_code_amd import _lib
     from floodplanet_code_amd.distributed import DataParallelTrainer
