@@ -143,6 +143,14 @@ struct Block {
   void* up = nullptr;         // BK_UP: upsampled + padded low-resolution input
   void* g_up = nullptr;
   UpTables upt;
+  // bilinear=False: ConvTranspose2d(ct_cin, ct_cout, 2, 2) run as a 3x3 conv over the zero-stuffed input
+  int ct_w = -1, ct_b = -1, ct_cin = 0, ct_cout = 0;
+  void* u = nullptr;          // zero-stuffed relu(bn(low)) at this block's resolution, ct_cin channels
+  void* g_u = nullptr;
+  float* ct_w3 = nullptr;     // embedded OIHW 3x3 weight [ct_cout][ct_cin][3][3] (fp32)
+  float* ct_dw3 = nullptr;    // its gradient
+  void* ct_wf = nullptr;      // packed forward / dgrad copies
+  void* ct_wd = nullptr;
   int first_param = 0, num_params = 0;  // contiguous range in the canonical parameter table
 };
 
@@ -320,10 +328,16 @@ int build_plan(fu_ctx* c) {
     else {
       const int k = i - 5;
       K.kind = BK_UP; K.skip = 3 - k; K.level = 3 - k;
-      cin = low + c->ch[3 - k]; cmid = cin / 2; cout = outs[k];
+      if (f.bilinear) { cin = low + c->ch[3 - k]; cmid = cin / 2; cout = outs[k]; }
+      else { K.ct_cin = low; K.ct_cout = low / 2; cin = low / 2 + c->ch[3 - k]; cmid = cout = outs[k]; }
       low = cout;
     }
     K.first_param = (int)c->params.size();
+    if (K.kind == BK_UP && !f.bilinear) {
+      const std::string up = "up" + std::to_string(i - 4) + ".up";
+      K.ct_w = add_param(c, up + ".weight", {K.ct_cin, K.ct_cout, 2, 2});
+      K.ct_b = add_param(c, up + ".bias", {K.ct_cout});
+    }
     const std::string pre = dc_prefix(i);
     for (int j = 0; j < 2; ++j) {
       Conv& v = K.c[j];
@@ -385,6 +399,17 @@ int alloc_workspace(fu_ctx* c) {
       const int clow = K.c[0].cin_real - c->ch[K.skip];
       A.want(&K.up, act(K.level, clow));
       A.want(&K.g_up, act(K.level, clow));
+      if (!f.bilinear) {
+        const int H = c->Hs[K.level], W = c->Ws[K.level];
+        A.want(&K.u, act(K.level, K.ct_cin));
+        A.want(&K.g_u, act(K.level, K.ct_cin));
+        A.want(&K.ct_w3, (size_t)9 * K.ct_cin * K.ct_cout * sizeof(float));
+        A.want(&K.ct_dw3, (size_t)9 * K.ct_cin * K.ct_cout * sizeof(float));
+        A.want(&K.ct_wf, conv3x3_pack_elems(c->prec, K.ct_cin, K.ct_cout) * es);
+        A.want(&K.ct_wd, conv3x3_pack_elems(c->prec, K.ct_cin, K.ct_cout) * es);
+        max_slab = std::max<int64_t>(max_slab, conv3x3_wgrad_slab_elems(c->prec, K.ct_cin, K.ct_cout, B, H, W));
+        max_dbp = std::max<int64_t>(max_dbp, (int64_t)2048 * K.ct_cout);
+      }
     }
   }
   const int64_t npix0 = (int64_t)B * f.height * f.width;
@@ -403,7 +428,7 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->adam_m, c->total_params * sizeof(float));
   A.want(&c->adam_v, c->total_params * sizeof(float));
   FU_TRY(A.commit());
-  for (int i = 5; i < 9; ++i) {
+  for (int i = 5; i < 9 && f.bilinear; ++i) {
     Block& K = c->blk[i];
     const int lowlvl = K.level + 1;
     FU_TRY(build_up_tables(c, c->Hs[lowlvl], c->Ws[lowlvl], &K.upt));
@@ -449,6 +474,13 @@ int repack(fu_ctx* c, hipStream_t s) {
     hipLaunchKernelGGL((k_pack_all<bf16_t, true>), dim3(grid), dim3(256), 0, s, c->P, t);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
+  if (!c->cfg.bilinear) {
+    for (int i = 5; i < 9; ++i) {
+      Block& K = c->blk[i];
+      FU_TRY(launch_convT_to_w3(P(c, K.ct_w), K.ct_cin, K.ct_cout, K.ct_w3, s));
+      FU_TRY(launch_pack_conv3x3(c->prec, K.ct_w3, K.ct_cout, K.ct_cin, K.ct_cin, K.ct_wf, K.ct_wd, s));
+    }
+  }
   c->packed_dirty = false;
   return 0;
 }
@@ -501,8 +533,17 @@ int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_
       FU_TRY(launch_maxpool2(c->prec, pv.y, pv.a, pv.b, K.pooled, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout, s));
     } else if (K.kind == BK_UP) {
       Conv& pv = c->blk[i - 1].c[1];
-      FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout,
-                              c->Hs[K.level], c->Ws[K.level], K.upt, s));
+      const int h = c->Hs[pv.level], w = c->Ws[pv.level], H = c->Hs[K.level], W = c->Ws[K.level];
+      if (c->cfg.bilinear) {
+        FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, h, w, pv.cout, H, W, K.upt, s));
+      } else {
+        // ConvTranspose2d(k2,s2) (unet.py:48-51) = 3x3 conv of the zero-stuffed input, then F.pad (unet.py:57-62)
+        FU_TRY(launch_zero_stuff(c->prec, pv.y, pv.a, pv.b, K.u, B, h, w, K.ct_cin, H, W, s));
+        ConvIn uin{K.u, K.ct_cin, nullptr, nullptr, nullptr, 0};
+        FU_TRY(launch_conv3x3(c->prec, uin, K.ct_wf, P(c, K.ct_b), K.up, K.ct_cout, nullptr, 0, nullptr, nullptr, B, H,
+                              W, s));
+        FU_TRY(launch_zero_border(c->prec, K.up, B, h, w, K.ct_cout, H, W, s));
+      }
     }
     FU_TRY(conv_fwd(c, i, 0, B, training, s));
     FU_TRY(conv_fwd(c, i, 1, B, training, s));
@@ -550,7 +591,21 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, sk.gy, sk.cout, K.g_up, v.cin_real - sk.cout, nullptr, nullptr,
                           B, H, W, s));
-    FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout, H, W, K.upt, s));
+    const int h = c->Hs[pv.level], w = c->Ws[pv.level];
+    if (c->cfg.bilinear) {
+      FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, h, w, pv.cout, H, W, K.upt, s));
+    } else {
+      FU_TRY(launch_zero_border(c->prec, K.g_up, B, h, w, K.ct_cout, H, W, s));      // F.pad region carries no gradient
+      int ndbp = 0;
+      FU_TRY(launch_channel_partial_sums(c->prec, K.g_up, K.ct_cout, (int64_t)B * H * W, c->db_part, &ndbp, s));
+      ConvIn uin{K.u, K.ct_cin, nullptr, nullptr, nullptr, 0};
+      FU_TRY(launch_conv3x3_wgrad(c->prec, uin, K.g_up, K.ct_cout, c->slab, K.ct_dw3, K.ct_cin, c->db_part, ndbp,
+                                  G(c, K.ct_b), B, H, W, s));
+      FU_TRY(launch_convT_grad_from_w3(K.ct_dw3, K.ct_cin, K.ct_cout, G(c, K.ct_w), s));
+      ConvIn gin{K.g_up, K.ct_cout, nullptr, nullptr, nullptr, 0};
+      FU_TRY(launch_conv3x3(c->prec, gin, K.ct_wd, nullptr, K.g_u, K.ct_cin, nullptr, 0, nullptr, nullptr, B, H, W, s));
+      FU_TRY(launch_gather_even(c->prec, K.g_u, pv.gy, B, h, w, K.ct_cin, H, W, s));
+    }
   }
   return 0;
 }
@@ -591,6 +646,11 @@ double conv_flops(fu_ctx* c, bool train) {
       if (i == 0 && j == 0) first = fl;
       fwd += fl;
     }
+  if (!c->cfg.bilinear)
+    for (int i = 5; i < 9; ++i) {
+      const Block& K = c->blk[i];
+      fwd += 2.0 * 4 * K.ct_cin * K.ct_cout * c->Hs[K.level + 1] * c->Ws[K.level + 1];
+    }
   fwd += 2.0 * c->cfg.base_channels * c->cfg.n_classes * c->cfg.height * c->cfg.width;
   return train ? 3.0 * fwd - first : fwd;
 }
@@ -616,10 +676,8 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   FU_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
   FU_REQUIRE(cfg->height >= 16 && cfg->width >= 16, "tile must be at least 16x16");
   FU_REQUIRE(cfg->precision == FU_F32 || cfg->precision == FU_BF16, "unknown precision %d", cfg->precision);
-  if (!cfg->bilinear) {
-    set_error("bilinear=0 (ConvTranspose2d upsampling) is not implemented in this build");
-    return FU_ERR_UNSUPPORTED;
-  }
+  FU_REQUIRE(cfg->bilinear || b == 64, "bilinear=0 exists only at base_channels 64 (the reference's UNetDecoder "
+             "channel plan is inconsistent for bilinear=False, unet.py:176-183)");
   FU_REQUIRE(cfg->precision == FU_F32 || b >= 8, "bf16 precision needs base_channels >= 8");
   FU_HIP_CHECK(hipSetDevice(cfg->device));
   fu_ctx* c = new (std::nothrow) fu_ctx();

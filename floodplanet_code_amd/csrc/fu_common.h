@@ -191,6 +191,18 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
 int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
                          const UpTables& t, hipStream_t s);
 
+// ConvTranspose2d(k2,s2) helpers (bilinear=False variant): zero-stuffing, even-position gather, pad-region zeroing,
+// bias-gradient partial sums, weight <-> embedded-3x3 conversions
+int launch_zero_stuff(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                      int outH, int outW, hipStream_t s);
+int launch_gather_even(Prec p, const void* gu, void* gsrc, int B, int H, int W, int C, int outH, int outW,
+                       hipStream_t s);
+int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, int outW, hipStream_t s);
+int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, float* partials, int* n_partials,
+                                hipStream_t s);
+int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t s);
+int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hipStream_t s);
+
 // head: 1x1 conv + bias on relu(a*y+b); logits fp32 NHWC [npix][ncls] (+ optional NCHW copy)
 int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const float* w, const float* bias, int C,
                     int ncls, int B, int H, int W, float* logits_nhwc, float* logits_nchw, hipStream_t s);

@@ -596,6 +596,193 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k=2, s=2) support (bilinear=False variant, unet.py:48-51).  The transposed conv is executed as
+// a 3x3 convolution of the zero-stuffed input (u[2y,2x] = x[y,x], zeros elsewhere) with the 2x2 kernel embedded in
+// the top-left taps, so forward / dgrad / wgrad reuse the MFMA conv kernels; these helpers do the data movement.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_zero_stuff(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
+                             T* __restrict__ dst, int H, int W, int C, int outH, int outW, int py0, int px0,
+                             int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ox = (int)(r % outW); r /= outW;
+    const int oy = (int)(r % outH);
+    const int64_t bb = r / outH;
+    float o[4] = {0, 0, 0, 0};
+    const int uy = oy - py0, ux = ox - px0;
+    if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W && !(uy & 1) && !(ux & 1)) {
+      float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+      const bool bn = a != nullptr;
+      if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
+      load_act4<T>(src + ((bb * H + (uy >> 1)) * W + (ux >> 1)) * (int64_t)C + cv * 4, av, bv, bn, o);
+    }
+    ElemIO<T>::store4(dst + idx * 4, o);
+  }
+}
+
+template <typename T>
+__global__ void k_gather_even(const T* __restrict__ gu, T* __restrict__ gsrc, int H, int W, int C, int outH, int outW,
+                              int py0, int px0, int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    int64_t r = idx / CV;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int64_t bb = r / H;
+    float v[4];
+    ElemIO<T>::load4(gu + ((bb * outH + py0 + 2 * iy) * outW + px0 + 2 * ix) * (int64_t)C + cv * 4, v);
+    ElemIO<T>::store4(gsrc + idx * 4, v);
+  }
+}
+
+// zero everything outside the [py0, py0+2H) x [px0, px0+2W) window of an outH x outW map (the F.pad region)
+template <typename T>
+__global__ void k_zero_border(T* __restrict__ t, int H2, int W2, int C, int outH, int outW, int py0, int px0,
+                              int64_t total) {
+  const int CV = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx / CV;
+    const int ox = (int)(r % outW); r /= outW;
+    const int oy = (int)(r % outH);
+    const int uy = oy - py0, ux = ox - px0;
+    if (uy < 0 || uy >= H2 || ux < 0 || ux >= W2) {
+      const float z[4] = {0, 0, 0, 0};
+      ElemIO<T>::store4(t + idx * 4, z);
+    }
+  }
+}
+
+// per-channel partial sums [nblk][C] of an NHWC tensor (bias gradient of the transposed conv)
+template <typename T>
+__global__ void k_channel_partial_sums(const T* __restrict__ g, int C, int64_t npix, float* __restrict__ partials) {
+  extern __shared__ float sm[];  // [rows][C]
+  const int CV = C >> 2;
+  const int rows = BNB_THREADS / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  if (row < rows) {
+    float sd[4] = {0, 0, 0, 0};
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < npix; p += (int64_t)gridDim.x * rows) {
+      float gv[4];
+      ElemIO<T>::load4(g + p * C + cv * 4, gv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sd[j] += gv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[row * C + cv * 4 + j] = sd[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += BNB_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += sm[r * C + c];
+    partials[(int64_t)blockIdx.x * C + c] = t;
+  }
+}
+
+// convT weight [Cin][Cout][2][2] -> OIHW 3x3 [Cout][Cin][3][3]: w3[a][b] = w[1-a][1-b] for a,b in {0,1}, else 0
+__global__ void k_convT_to_w3(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ w3, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % 9);
+    const int64_t r = idx / 9;
+    const int ci = (int)(r % Cin);
+    const int co = (int)(r / Cin);
+    const int a = tap / 3, b = tap % 3;
+    w3[idx] = (a < 2 && b < 2) ? w[(((int64_t)ci * Cout + co) * 2 + (1 - a)) * 2 + (1 - b)] : 0.f;
+  }
+}
+__global__ void k_convT_grad_from_w3(const float* __restrict__ dw3, int Cin, int Cout, float* __restrict__ dw,
+                                     int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int kx = (int)(idx & 1), ky = (int)((idx >> 1) & 1);
+    const int64_t r = idx >> 2;
+    const int co = (int)(r % Cout);
+    const int ci = (int)(r / Cout);
+    dw[idx] = dw3[((int64_t)co * Cin + ci) * 9 + (1 - ky) * 3 + (1 - kx)];
+  }
+}
+
+int launch_zero_stuff(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
+                      int outH, int outW, hipStream_t s) {
+  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+  const int64_t total = (int64_t)B * outH * outW * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_zero_stuff<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C,
+                       outH, outW, py0, px0, total);
+  else
+    hipLaunchKernelGGL(k_zero_stuff<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
+                       outH, outW, py0, px0, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gather_even(Prec p, const void* gu, void* gsrc, int B, int H, int W, int C, int outH, int outW,
+                       hipStream_t s) {
+  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_gather_even<float>, dim3(g), dim3(256), 0, s, (const float*)gu, (float*)gsrc, H, W, C, outH,
+                       outW, py0, px0, total);
+  else
+    hipLaunchKernelGGL(k_gather_even<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)gsrc, H, W, C, outH,
+                       outW, py0, px0, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, int outW, hipStream_t s) {
+  if (outH == 2 * H && outW == 2 * W) return 0;
+  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+  const int64_t total = (int64_t)B * outH * outW * (C / 4);
+  const int g = grid_for(total, 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_zero_border<float>, dim3(g), dim3(256), 0, s, (float*)t, 2 * H, 2 * W, C, outH, outW, py0, px0,
+                       total);
+  else
+    hipLaunchKernelGGL(k_zero_border<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)t, 2 * H, 2 * W, C, outH, outW, py0,
+                       px0, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, float* partials, int* n_partials,
+                                hipStream_t s) {
+  FU_REQUIRE(C % 4 == 0 && C <= 1024, "channel_sum: channels must be a multiple of 4 and <= 1024");
+  const int rows = BNB_THREADS / (C >> 2);
+  int64_t nb = ceil_div64(npix, (int64_t)rows * 8);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  const size_t sh = (size_t)rows * C * sizeof(float);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL(k_channel_partial_sums<float>, dim3((unsigned)nb), dim3(BNB_THREADS), sh, s, (const float*)g, C,
+                       npix, partials);
+  else
+    hipLaunchKernelGGL(k_channel_partial_sums<bf16_t>, dim3((unsigned)nb), dim3(BNB_THREADS), sh, s, (const bf16_t*)g,
+                       C, npix, partials);
+  FU_LAUNCH_CHECK();
+  *n_partials = (int)nb;
+  return 0;
+}
+int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t s) {
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(k_convT_to_w3, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, w, Cin, Cout, w3, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hipStream_t s) {
+  const int64_t total = (int64_t)Cin * Cout * 4;
+  hipLaunchKernelGGL(k_convT_grad_from_w3, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, dw3, Cin, Cout, dw, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // head: logits[p][k] = bias[k] + sum_c relu(a*y+b)[p][c] * w[k][c]      (OutConv, unet.py:74-77)
 // LPP = C/4 lanes cooperate on one pixel (16 for C = 64); partial dot products meet through wave shuffles.
 // ------------------------------------------------------------------------------------------------
