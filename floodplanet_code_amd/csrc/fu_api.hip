@@ -760,9 +760,15 @@ int fu_loss_ce(fu_ctx* c, const int64_t* target, int ignore_index, float* loss_o
 
 int fu_loss_bce_dice(fu_ctx* c, const int64_t* target, int ignore_index, float dice_weight, float* loss_out,
                      fu_stream stream) {
-  (void)c; (void)target; (void)ignore_index; (void)dice_weight; (void)loss_out; (void)stream;
-  set_error("fu_loss_bce_dice is not implemented in this build");
-  return FU_ERR_UNSUPPORTED;
+  FU_REQUIRE(c && target, "fu_loss_bce_dice: null argument");
+  FU_REQUIRE(c->last_batch > 0, "fu_loss_bce_dice: no forward pass yet");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)c->last_batch * c->cfg.height * c->cfg.width;
+  FU_TRY(launch_bce_dice(c->logits, target, c->cfg.n_classes, ignore_index, npix, dice_weight, c->ce_part,
+                         c->loss_dev + 8, loss_out ? loss_out : c->loss_dev, c->n_valid,
+                         c->fwd_training ? c->dlogits : nullptr, s));
+  if (c->fwd_training) c->have_loss = true;
+  return FU_OK;
 }
 
 int fu_num_blocks(const fu_ctx* c) { (void)c; return 10; }

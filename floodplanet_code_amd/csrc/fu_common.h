@@ -214,6 +214,10 @@ int launch_ce_loss(const float* logits_nhwc, const int64_t* target, int ncls, in
 // dlogits (NHWC fp32) from CE: (softmax - onehot)/n_valid on valid pixels
 int launch_ce_grad(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
                    const int64_t* n_valid_dev, float* dlogits_nhwc, hipStream_t s);
+// BCE + soft Dice on softmax(z)[1]; partials >= 5*400 floats, coef 4 floats; dlogits may be null (eval)
+int launch_bce_dice(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                    float dice_w, float* partials, float* coef, float* loss_out, int64_t* n_valid_dev,
+                    float* dlogits_nhwc, hipStream_t s);
 int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int ncls, int B, int H, int W,
                              hipStream_t s);
 // head backward: G[y] = dlogits * W ; dW = sum dlogits (x) z ; db = sum dlogits

@@ -980,6 +980,136 @@ int launch_ce_grad(const float* logits_nhwc, const int64_t* target, int ncls, in
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BCE + soft Dice on p = softmax(z)[1] (north-star extension; the reference has no such loss -> parity is pinned
+// only by oracle/unet_oracle.py:bce_dice_loss).  All spatial reductions in fp32 registers + wave shuffles, fp64 finalize.
+//   BCE  = -(1/N) sum_valid [ t log p + (1-t) log(1-p) ],  Dice = 1 - (2 sum p t + 1) / (sum p + sum t + 1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bd_pixel(const float* z, int ncls, float& p, float& logp, float& log1mp, float* s,
+                                         float* s1) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) m = fmaxf(m, z[k]);
+  float se = 0.f, se1 = 0.f;
+  float e[HEAD_MAX_CLS];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+    e[k] = k < ncls ? expf(z[k] - m) : 0.f;
+    se += e[k];
+    if (k != 1) se1 += e[k];
+  }
+  const float inv = 1.f / se, inv1 = se1 > 0.f ? 1.f / se1 : 0.f;
+#pragma unroll
+  for (int k = 0; k < HEAD_MAX_CLS; ++k) { s[k] = e[k] * inv; s1[k] = (k != 1) ? e[k] * inv1 : 0.f; }
+  p = s[1];
+  const float lse = logf(se);
+  logp = (z[1] - m) - lse;
+  log1mp = logf(se1) - lse;
+}
+
+__global__ void k_bd_loss(const float* __restrict__ logits, const int64_t* __restrict__ target, int ncls,
+                          int ignore_index, int64_t npix, float* __restrict__ partials) {
+  __shared__ float wsum[CE_BLOCK / 64][5];
+  float acc[5] = {0, 0, 0, 0, 0};  // bce, p*t, p, t, n
+  for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tg = target[px];
+    if (tg != (int64_t)ignore_index && tg >= 0 && tg < ncls) {
+      float z[HEAD_MAX_CLS], s[HEAD_MAX_CLS], s1[HEAD_MAX_CLS];
+#pragma unroll
+      for (int k = 0; k < HEAD_MAX_CLS; ++k) z[k] = k < ncls ? logits[px * ncls + k] : -INFINITY;
+      float p, lp, l1p;
+      bd_pixel(z, ncls, p, lp, l1p, s, s1);
+      const float t = tg == 1 ? 1.f : 0.f;
+      acc[0] -= t > 0.f ? lp : l1p;
+      acc[1] += p * t; acc[2] += p; acc[3] += t; acc[4] += 1.f;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float v = wave_sum(acc[j]);
+    if ((threadIdx.x & 63) == 0) wsum[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+    for (int wv = 0; wv < CE_BLOCK / 64; ++wv) t += wsum[wv][threadIdx.x];
+    partials[blockIdx.x * 5 + threadIdx.x] = t;
+  }
+}
+
+// coef: [0] = 1/N (0 if N == 0), [1] = D, [2] = 2I+1, [3] = dice weight
+__global__ __launch_bounds__(256) void k_bd_finalize(const float* __restrict__ partials, int nblk, float dice_w,
+                                                     float* __restrict__ loss_out, float* __restrict__ coef,
+                                                     int64_t* __restrict__ n_valid_dev) {
+  __shared__ double sm[5][256];
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblk; i += 256)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a[j] += (double)partials[i * 5 + j];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) sm[j][threadIdx.x] = a[j];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) sm[j][threadIdx.x] += sm[j][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double bce = sm[0][0], I = sm[1][0], Sp = sm[2][0], St = sm[3][0], N = sm[4][0];
+    const double D = Sp + St + 1.0, Nn = 2.0 * I + 1.0;
+    const double loss = N > 0.0 ? bce / N + (double)dice_w * (1.0 - Nn / D) : 0.0;
+    if (loss_out) *loss_out = (float)loss;
+    coef[0] = N > 0.0 ? (float)(1.0 / N) : 0.f;
+    coef[1] = (float)D; coef[2] = (float)Nn; coef[3] = N > 0.0 ? dice_w : 0.f;
+    *n_valid_dev = (int64_t)(N + 0.5);
+  }
+}
+
+__global__ void k_bd_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, int ncls,
+                          int ignore_index, int64_t npix, const float* __restrict__ coef, float* __restrict__ dl) {
+  const float invN = coef[0], D = coef[1], Nn = coef[2], w = coef[3];
+  for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tg = target[px];
+    const bool valid = tg != (int64_t)ignore_index && tg >= 0 && tg < ncls && invN > 0.f;
+    float z[HEAD_MAX_CLS], s[HEAD_MAX_CLS], s1[HEAD_MAX_CLS];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) z[k] = k < ncls ? logits[px * ncls + k] : -INFINITY;
+    float p, lp, l1p;
+    bd_pixel(z, ncls, p, lp, l1p, s, s1);
+    const float t = tg == 1 ? 1.f : 0.f;
+    const float ddice = -(2.f * t * D - Nn) / (D * D);   // d Dice / d p
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+      if (k < ncls) {
+        const float d1 = k == 1 ? 1.f : 0.f;
+        const float gb = (s[k] - t * d1 - (1.f - t) * s1[k]) * invN;
+        const float gd = w * ddice * p * (d1 - s[k]);
+        dl[px * ncls + k] = valid ? gb + gd : 0.f;
+      }
+    }
+  }
+}
+
+int launch_bce_dice(const float* logits_nhwc, const int64_t* target, int ncls, int ignore_index, int64_t npix,
+                    float dice_w, float* partials, float* coef, float* loss_out, int64_t* n_valid_dev,
+                    float* dlogits_nhwc, hipStream_t s) {
+  FU_REQUIRE(ncls >= 2, "bce_dice needs n_classes >= 2 (class 1 = flood)");
+  const int nblk = grid_for(npix, CE_BLOCK, 400);   // 5 floats per block must fit the 2*1024-float partial buffer
+  hipLaunchKernelGGL(k_bd_loss, dim3(nblk), dim3(CE_BLOCK), 0, s, logits_nhwc, target, ncls, ignore_index, npix,
+                     partials);
+  FU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bd_finalize, dim3(1), dim3(256), 0, s, partials, nblk, dice_w, loss_out, coef, n_valid_dev);
+  FU_LAUNCH_CHECK();
+  if (dlogits_nhwc) {
+    hipLaunchKernelGGL(k_bd_grad, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, s, logits_nhwc, target, ncls,
+                       ignore_index, npix, coef, dlogits_nhwc);
+    FU_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 __global__ void k_dlogits_from_nchw(const float* __restrict__ src, float* __restrict__ dst, int ncls, int HW,
                                     int64_t total) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;

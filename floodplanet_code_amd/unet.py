@@ -247,10 +247,17 @@ class HipUNet(nn.Module):
         check(lib.fu_forward(ctx, ptr(x), B, int(training), ptr(logits), self._stream(x.device)))
         return logits
 
-    def _loss_raw(self, target: torch.Tensor, ignore_index: int, device) -> torch.Tensor:
+    def _loss_raw(self, target: torch.Tensor, ignore_index: int, device, kind: str = "ce",
+                  dice_weight: float = 1.0) -> torch.Tensor:
         lib = _lib.load()
         target = target.contiguous().long()
         loss = torch.empty((), dtype=torch.float32, device=device)
+        if kind == "bce_dice":
+            check(lib.fu_loss_bce_dice(self._ctx, ptr(target), int(ignore_index), float(dice_weight), ptr(loss),
+                                       self._stream(device)))
+            return loss
+        if kind != "ce":
+            raise ValueError(f"unknown loss kind {kind!r}")
         if self._confusion is None or self._confusion.device != device:
             self._confusion = torch.zeros(self.n_classes * self.n_classes, dtype=torch.int64, device=device)
         check(lib.fu_loss_ce(self._ctx, ptr(target), int(ignore_index), ptr(loss), ptr(self._confusion), None,
@@ -278,21 +285,24 @@ class HipUNet(nn.Module):
         return self._forward_raw(x, self.training)
 
     def loss(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int,
-             return_logits: bool = False):
-        """Fused forward + CrossEntropyLoss(ignore_index) (+ NaN guard) of water_seg_model.py:101-106.
+             return_logits: bool = False, kind: str = "ce", dice_weight: float = 1.0):
+        """Fused forward + CrossEntropyLoss(ignore_index) (+ NaN guard) of water_seg_model.py:101-106
+        (kind='ce', the reference's loss) or the BCE + soft-Dice extension (kind='bce_dice').
         The returned loss is differentiable: ``loss.backward()`` runs the HIP backward."""
         if self.training and torch.is_grad_enabled():
             params = [p for _, p, _, _ in self._table]
-            out = _UNetLossFn.apply(self, x, target, int(ignore_index), bool(return_logits), *params)
+            out = _UNetLossFn.apply(self, x, target, int(ignore_index), bool(return_logits), kind,
+                                    float(dice_weight), *params)
             return out if return_logits else out[0]
         logits = self._forward_raw(x, self.training, want_logits=return_logits)
-        loss = self._loss_raw(target, ignore_index, x.device)
+        loss = self._loss_raw(target, ignore_index, x.device, kind, dice_weight)
         return (loss, logits) if return_logits else loss
 
-    def train_step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int, kind: str = "ce",
+                   dice_weight: float = 1.0) -> torch.Tensor:
         """forward + loss + backward without autograd; gradients land in the flat buffer / p.grad."""
         self._forward_raw(x, True, want_logits=False)
-        loss = self._loss_raw(target, ignore_index, x.device)
+        loss = self._loss_raw(target, ignore_index, x.device, kind, dice_weight)
         self._backward_raw(None, x.device)
         self.attach_grads()
         return loss
@@ -338,11 +348,11 @@ class _UNetLossFn(torch.autograd.Function):
     """(loss, logits) = CE(f(x; params), target): the fused training_step path."""
 
     @staticmethod
-    def forward(ctx, module: HipUNet, x, target, ignore_index, want_logits, *params):
+    def forward(ctx, module: HipUNet, x, target, ignore_index, want_logits, kind, dice_weight, *params):
         ctx.module = module
         ctx.device = x.device
         logits = module._forward_raw(x, True, want_logits=want_logits)
-        loss = module._loss_raw(target, ignore_index, x.device)
+        loss = module._loss_raw(target, ignore_index, x.device, kind, dice_weight)
         if logits is None:
             logits = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(logits)
@@ -353,4 +363,4 @@ class _UNetLossFn(torch.autograd.Function):
         m = ctx.module
         m._backward_raw(None, ctx.device)
         grads = tuple(g * dloss for g in m.grad_views())
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + grads

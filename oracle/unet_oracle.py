@@ -260,6 +260,30 @@ def ce_loss(logits: torch.Tensor, target: torch.Tensor, ignore_index: int) -> to
     return loss
 
 
+def bce_dice_loss(logits: torch.Tensor, target: torch.Tensor, ignore_index: int, dice_weight: float = 1.0):
+    """North-star EXTENSION, PARITY UNPINNED BY THE REFERENCE (the reference has no Dice/BCE anywhere,
+    SURVEY.md section 0.1): per-pixel binary cross entropy + soft Dice on p = softmax(logits)[:, 1] (flood class)
+    against t = [target == 1], over pixels whose target != ignore_index:
+        BCE  = -(1/N) sum [t log p + (1-t) log(1-p)]
+        Dice = 1 - (2 sum p t + 1) / (sum p + sum t + 1)
+    all-ignored batch -> 0.  This definition IS the specification the HIP kernels are tested against."""
+    logp_all = F.log_softmax(logits, dim=1)
+    p = logp_all[:, 1].exp()
+    logp = logp_all[:, 1]
+    others = torch.cat([logits[:, :1], logits[:, 2:]], dim=1)
+    log1mp = torch.logsumexp(others, dim=1) - torch.logsumexp(logits, dim=1)
+    valid = (target != ignore_index) & (target >= 0) & (target < logits.shape[1])
+    n = valid.sum()
+    if int(n) == 0:
+        return logits.sum() * 0.0
+    t = (target == 1).to(logits.dtype)
+    v = valid.to(logits.dtype)
+    bce = -((t * logp + (1 - t) * log1mp) * v).sum() / n
+    inter = (p * t * v).sum()
+    dice = 1 - (2 * inter + 1) / ((p * v).sum() + (t * v).sum() + 1)
+    return bce + dice_weight * dice
+
+
 def resolve_ignore_index(ignore_index: int, n_classes: int) -> int:
     """water_seg_model.py:35-36."""
     return n_classes - 1 if ignore_index == -1 else ignore_index
@@ -325,8 +349,8 @@ def adam_update(st, grads, opt, lr):
 
 
 def loss_and_grads(st, batch, ignore_index, bilinear=True, early_fusion=False,
-                   training=True):
-    """forward + CE + autograd backward.  Returns (logits, loss, grads dict)."""
+                   training=True, loss_kind="ce", dice_weight=1.0):
+    """forward + loss + autograd backward.  Returns (logits, loss, grads dict)."""
     names = trainable_names(st)
     leaves = {}
     work = dict(st)
@@ -336,7 +360,10 @@ def loss_and_grads(st, batch, ignore_index, bilinear=True, early_fusion=False,
     x = assemble_input(batch, early_fusion)
     logits = unet_forward(work, x, training, bilinear)
     # running buffers were updated in `work` (same tensor objects as st) -> nothing to copy back
-    loss = ce_loss(logits, batch["target"], ignore_index)
+    if loss_kind == "ce":
+        loss = ce_loss(logits, batch["target"], ignore_index)
+    else:
+        loss = bce_dice_loss(logits, batch["target"], ignore_index, dice_weight)
     loss.backward()
     grads = {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k]))
              for k in names}

@@ -304,3 +304,27 @@ def test_bf16_training_trajectory_tracks_fp32():
     assert l32[-1] < 0.5 * l32[0] and l16[-1] < 0.5 * l16[0]
     assert abs(l16[-1] - l32[-1]) <= 0.15 * l32[0]
     assert abs(a16 - a32) <= 0.05
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_bce_dice_extension_matches_its_oracle(prec, tol):
+    """North-star extension (no reference counterpart): BCE + soft Dice, fp32 wave-shuffle reductions.
+    Checked against oracle.bce_dice_loss through the whole net (loss value, gradients)."""
+    st = O.make_state(8, 3, 16, True, seed=2)
+    batch = O.make_batch(2, 8, 64, 64, seed=4, n_label_values=3)
+    st_o = {k: v.clone() for k, v in st.items()}
+    _, loss_o, grads_o = O.loss_and_grads(st_o, batch, 0, loss_kind="bce_dice", dice_weight=0.7)
+    net = HipUNet(8, 3, base_channels=16, precision=prec)
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    loss = net.loss(batch["image"].to(DEV), batch["target"].to(DEV), 0, kind="bce_dice", dice_weight=0.7)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_o.item()) <= tol * 3
+    if prec == "fp32":
+        for k, p in net.named_parameters():
+            if not is_dead_bias(k):
+                assert rel(p.grad.cpu(), grads_o[k]) <= GRAD_TOL, k
+    # all-ignored -> exactly zero loss and gradients
+    lz = net.train_step(batch["image"].to(DEV), torch.zeros_like(batch["target"]).to(DEV), 0, kind="bce_dice")
+    assert lz.item() == 0.0 and float(net.flat_grads().abs().max()) == 0.0
