@@ -875,6 +875,15 @@ int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* tota
   return FU_OK;
 }
 
+int fu_augment(const float* image, const int64_t* target, float* image_out, int64_t* target_out, const int32_t* flags,
+               const float* angles_deg, int B, int C, int H, int W, int64_t target_fill, fu_stream stream) {
+  FU_REQUIRE(image && image_out && flags && angles_deg, "fu_augment: null argument");
+  FU_REQUIRE((target == nullptr) == (target_out == nullptr), "fu_augment: target and target_out go together");
+  FU_REQUIRE(image != image_out && (!target || target != target_out), "fu_augment: in-place operation is not supported");
+  return launch_augment(image, target, image_out, target_out, flags, angles_deg, B, C, H, W, target_fill,
+                        (hipStream_t)stream);
+}
+
 // ---- single operators --------------------------------------------------------------------------------
 int fu_elem_size(int precision) { return precision == FU_F32 ? 4 : 2; }
 

@@ -1229,6 +1229,54 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// On-GPU tile augmentation (datasets/base_dataset.py:494-555): per sample hflip -> vflip -> rotate(angle) with
+// torchvision's tensor semantics (nearest, expand=False, centre = image centre, zero fill), applied identically to
+// the image [B,C,H,W] fp32 and the target [B,H,W] int64.  One gather pass: the three transforms are composed into a
+// single source coordinate per output pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_augment(const float* __restrict__ img, const int64_t* __restrict__ tgt, float* __restrict__ img_o,
+                          int64_t* __restrict__ tgt_o, const int* __restrict__ flags, const float* __restrict__ angle,
+                          int C, int H, int W, int64_t target_fill, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % W);
+    const int64_t r = idx / W;
+    const int oy = (int)(r % H);
+    const int b = (int)(r / H);
+    const int f = flags[b];
+    int sx = ox, sy = oy;
+    bool inside = true;
+    if (f & 4) {
+      // torchvision F.rotate -> affine_grid + grid_sample(nearest, align_corners=False)
+      const float th = angle[b] * 0.017453292519943295f;
+      const float cs = cosf(th), sn = sinf(th);
+      const float xc = (float)ox + 0.5f - 0.5f * (float)W, yc = (float)oy + 0.5f - 0.5f * (float)H;
+      const float xs = cs * xc - sn * yc + 0.5f * (float)W - 0.5f;
+      const float ys = sn * xc + cs * yc + 0.5f * (float)H - 0.5f;
+      sx = (int)nearbyintf(xs);
+      sy = (int)nearbyintf(ys);
+      inside = sx >= 0 && sx < W && sy >= 0 && sy < H;
+    }
+    if (f & 2) sy = H - 1 - sy;   // the rotate input is the v-flipped, h-flipped tile
+    if (f & 1) sx = W - 1 - sx;
+    if (tgt_o) tgt_o[idx] = inside ? tgt[((int64_t)b * H + sy) * W + sx] : target_fill;
+    for (int c = 0; c < C; ++c) {
+      const int64_t o = (((int64_t)b * C + c) * H + oy) * W + ox;
+      img_o[o] = inside ? img[(((int64_t)b * C + c) * H + sy) * W + sx] : 0.f;
+    }
+  }
+}
+
+int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
+                   const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s) {
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(k_augment, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, img, tgt, img_o, tgt_o, flags, angle,
+                     C, H, W, target_fill, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor update order; water_seg_model.py:200)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

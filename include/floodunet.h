@@ -18,6 +18,8 @@
  *   fu_backward[_block]         loss.backward() issued by Lightning's automatic optimisation
  *                                                                            st_water_seg/fit.py:95-97
  *   fu_adam_step                optim.Adam(self.parameters(), lr).step()     st_water_seg/models/water_seg_model.py:198-205
+ *   fu_augment                  torchvision hflip / vflip / rotate of sample_transforms + apply_transforms
+ *                                                                            st_water_seg/datasets/base_dataset.py:494-555
  *   fu_block_param_range        (new) gradient bucket of one backward block, for RCCL all-reduce overlap
  *   fu_op_*                     single operators for per-op parity tests (conv2d, batch_norm, max_pool2d,
  *                               upsample, cross_entropy as used in unet.py / water_seg_model.py)
@@ -114,7 +116,9 @@ int fu_forward(fu_ctx* ctx, const float* x, int batch, int training, float* logi
  * (argmax prediction), ADDED to the existing contents.  n_valid_out: optional device int64 scalar. */
 int fu_loss_ce(fu_ctx* ctx, const int64_t* target, int ignore_index, float* loss_out, int64_t* confusion_out,
                int64_t* n_valid_out, fu_stream stream);
-/* North-star extension (no reference counterpart): BCE on softmax p(class 1) + soft Dice, fp32 reductions. */
+/* North-star extension (no reference counterpart; specification = oracle/unet_oracle.py:bce_dice_loss):
+ * BCE on p = softmax(z)[1] vs [target == 1] + dice_weight * soft Dice, over target != ignore_index, fp32 wave-shuffle
+ * reductions; stores its logits gradient for fu_backward like fu_loss_ce. */
 int fu_loss_bce_dice(fu_ctx* ctx, const int64_t* target, int ignore_index, float dice_weight, float* loss_out,
                      fu_stream stream);
 
@@ -134,6 +138,15 @@ int fu_adam_step(fu_ctx* ctx, float lr, float beta1, float beta2, float eps, int
                  fu_stream stream);
 int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* device pointers, for checkpoints */
 int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
+
+/* ---- on-GPU tile augmentation (datasets/base_dataset.py:494-555) ------- */
+/* Per sample b: hflip (flags[b] & 1), then vflip (& 2), then rotate by angles_deg[b] (& 4) with torchvision's
+ * tensor semantics (nearest, expand=False, centre = image centre, image fill 0), applied identically to
+ * image fp32 NCHW [B,C,H,W] and target int64 [B,H,W] (fill = target_fill; the reference fills 0).  Out of place.
+ * The random draws (which transforms, which angle) stay on the host, as in sample_transforms(). */
+enum { FU_AUG_HFLIP = 1, FU_AUG_VFLIP = 2, FU_AUG_ROTATE = 4 };
+int fu_augment(const float* image, const int64_t* target, float* image_out, int64_t* target_out, const int32_t* flags,
+               const float* angles_deg, int B, int C, int H, int W, int64_t target_fill, fu_stream stream);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 int64_t fu_workspace_bytes(const fu_ctx* ctx);

@@ -318,6 +318,37 @@ def metrics_from_counts(m: np.ndarray) -> Dict[str, float]:
 
 
 # --------------------------------------------------------------------------- #
+# augmentation (datasets/base_dataset.py:494-555 -> torchvision F.hflip / F.vflip / F.rotate)
+# --------------------------------------------------------------------------- #
+def augment(image: np.ndarray, target: np.ndarray, flag: int, angle_deg: float, target_fill: int = 0):
+    """hflip (flag & 1) -> vflip (& 2) -> rotate (& 4) of ONE sample, image [C,H,W], target [H,W].
+    PARITY UNPINNED: torchvision is absent; the rotate restates its tensor path (v0.13, the version range of
+    environment.yml): _get_inverse_affine_matrix(centre 0, -angle) -> affine_grid with half-pixel centres ->
+    grid_sample(nearest, align_corners=False, zeros): source = R(angle) * (dst + 0.5 - size/2) + size/2 - 0.5,
+    rounded half-to-even, zero fill outside."""
+    img, tgt = image, target
+    if flag & 1:
+        img, tgt = img[:, :, ::-1], tgt[:, ::-1]
+    if flag & 2:
+        img, tgt = img[:, ::-1, :], tgt[::-1, :]
+    if flag & 4:
+        C, H, W = img.shape
+        th = np.float32(angle_deg) * np.float32(0.017453292519943295)
+        cs, sn = np.cos(th, dtype=np.float32), np.sin(th, dtype=np.float32)
+        oy, ox = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        xc = ox + np.float32(0.5) - np.float32(0.5 * W)
+        yc = oy + np.float32(0.5) - np.float32(0.5 * H)
+        xs = cs * xc - sn * yc + np.float32(0.5 * W) - np.float32(0.5)
+        ys = sn * xc + cs * yc + np.float32(0.5 * H) - np.float32(0.5)
+        sx, sy = np.rint(xs).astype(np.int64), np.rint(ys).astype(np.int64)
+        inside = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+        sxc, syc = np.clip(sx, 0, W - 1), np.clip(sy, 0, H - 1)
+        img = np.where(inside[None], np.ascontiguousarray(img)[:, syc, sxc], 0).astype(image.dtype)
+        tgt = np.where(inside, np.ascontiguousarray(tgt)[syc, sxc], target_fill).astype(target.dtype)
+    return np.ascontiguousarray(img), np.ascontiguousarray(tgt)
+
+
+# --------------------------------------------------------------------------- #
 # training step (what Lightning's automatic optimisation does around training_step)
 # --------------------------------------------------------------------------- #
 def trainable_names(st: Dict[str, torch.Tensor], n_channels=None) -> List[str]:

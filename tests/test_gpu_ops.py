@@ -269,3 +269,29 @@ def test_bf16_memory_bound_ops():
     u = F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=True)
     ref = F.pad(u, [0, 1, 0, 1])
     assert rel_err(nchw_bf(up), ref) < 3e-3
+
+
+def test_gpu_augmentation_matches_oracle_and_flip_identities():
+    from floodplanet_code_amd import augment
+    from oracle import unet_oracle as O
+    g = torch.Generator().manual_seed(6)
+    B, Cc, H, W = 6, 5, 40, 56
+    img = torch.rand(B, Cc, H, W, generator=g)
+    tgt = torch.randint(0, 3, (B, H, W), generator=g)
+    flags = [0, 1, 2, 3, 4, 7]
+    angles = [0.0, 0.0, 0.0, 0.0, 33.0, 211.5]
+    out, tout = augment.apply(img.to(DEV), tgt.to(DEV), flags, angles, target_fill=0)
+    torch.cuda.synchronize()
+    out, tout = out.cpu(), tout.cpu()
+    assert torch.equal(out[0], img[0]) and torch.equal(tout[0], tgt[0])
+    assert torch.equal(out[1], img[1].flip(-1)) and torch.equal(tout[1], tgt[1].flip(-1))
+    assert torch.equal(out[2], img[2].flip(-2)) and torch.equal(tout[2], tgt[2].flip(-2))
+    assert torch.equal(out[3], img[3].flip(-1).flip(-2))
+    for b in (4, 5):
+        ri, rt = O.augment(img[b].numpy(), tgt[b].numpy(), flags[b], angles[b], 0)
+        mism = (out[b].numpy() != ri).any(0) | (tout[b].numpy() != rt)
+        assert mism.mean() < 2e-3     # cosf/sinf vs numpy may flip a rounding tie on a few pixels
+    # a 90 degree rotation of a square tile is an exact rot90
+    sq = torch.rand(1, 2, 32, 32, generator=g)
+    o2, _ = augment.apply(sq.to(DEV), None, [4], [90.0])
+    assert torch.equal(o2.cpu()[0], torch.rot90(sq[0], 1, dims=(-2, -1)))
