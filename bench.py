@@ -36,7 +36,7 @@ def parse():
                     help="bf16 = BASELINE.json configs[1] (default); f32 = the 1e-4 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
 
 

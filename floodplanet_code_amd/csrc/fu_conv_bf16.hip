@@ -236,9 +236,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
 
   // fragment base offsets (bf16 elements)
   int aoff[2], boff[NTW];
+  // m-tile = 2 image rows x 16 columns.  Lanes 16..31 (second row) take their columns ROTATED by HWd mod 16:
+  // the halo pitch (18 pixels) would otherwise put rows 12..15 of the first image row and 4..11 of the second on the
+  // same LDS bank slots inside every 16-lane ds_read_b128 group (2-way conflict on each A read; measured 38 % of the
+  // LDS-active cycles).  With the rotation the 16 lanes of a group hit 16 distinct slots.
+  const int mrow = l31 >> 4;
+  const int mcol = mrow ? ((l31 - 16 - (HWd & 15)) & 15) : l31;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
-    aoff[mt] = (((wm * 2 + mt) * 2 + (l31 >> 4)) * HWd + (l31 & 15)) * KCP + 8 * lh;
+    aoff[mt] = (((wm * 2 + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) boff[nt] = (wn * 32 * NTW + nt * 32 + l31) * KCP + 8 * lh;
 
@@ -297,9 +303,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float a = acc[mt][nt][4 * g + k];
-          const int p = k + 8 * g + 4 * lh;
+          const int p = k + 8 * g + 4 * lh;                       // MFMA row -> pixel (second row rotated, see aoff)
           const int oy = y0 + (wm * 2 + mt) * 2 + (p >> 4);
-          const int ox = x0 + (p & 15);
+          const int ox = x0 + ((p >> 4) ? ((p - 16 - (HWd & 15)) & 15) : p);
           if (nok && oy < P.H && ox < P.W) { ssum[nt] += a; ssq[nt] += a * a; }
           v[k] = a + bias;
         }
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
         o.y = q_lo ? recv : Bq;
         const int p = qj + 8 * g + 4 * lh;       // this lane now owns pixel row qj of the register quad
         const int oy = y0 + (wm * 2 + mt) * 2 + (p >> 4);
-        const int ox = x0 + (p & 15);
+        const int ox = x0 + ((p >> 4) ? ((p - 16 - (HWd & 15)) & 15) : p);
         if (nq < P.N && oy < P.H && ox < P.W)
           *reinterpret_cast<uint2*>(dst + (((int64_t)bb * P.H + oy) * P.W + ox) * dstride + dn) = o;
       }
