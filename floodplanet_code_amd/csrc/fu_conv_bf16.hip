@@ -255,25 +255,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
     store_chunk(ch * KC);
     __syncthreads();
     if (ch + 1 < nChunks) load_chunk((ch + 1) * KC);   // raw loads stay in flight under the MFMA block
+    // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
+    // s+1 are requested from LDS before the MFMAs of step s are issued (hipcc otherwise issues each step's
+    // ds_reads just in time and exposes one LDS latency per 4 MFMAs).
+    bf16x8 af[2][2], bfr[2][NTW];
+    auto load_frags = [&](auto Sc, auto Bc) {
+      constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
+      constexpr int tap = st >> 1, ks = st & 1;
+      constexpr int toff = ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3) * HWd + (tap % 3)) * KCP;
+      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2], bfr[NTW];
+      for (int nt = 0; nt < NTW; ++nt)
+        bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+    };
+    load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<0, 18>([&](auto S) {
+      constexpr int st = decltype(S)::value, buf = st & 1;
+      if constexpr (st + 1 < 18) {
+        load_frags(std::integral_constant<int, st + 1>{}, std::integral_constant<int, buf ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
+      }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          af[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff + ks * 16);
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          bfr[nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
-      }
-    }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
+    });
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
