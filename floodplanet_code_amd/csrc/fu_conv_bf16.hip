@@ -579,17 +579,33 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
     store_tile();
     __syncthreads();
     if (pt + 1 < pt1) load_tile(pt + 1);   // in flight under the MFMA block
-#pragma unroll
-    for (int r = 0; r < PTH; ++r) {
+    // Walk the halo rows once: the X fragment of (halo row hr, column shift dx) feeds up to three taps
+    // (dy = 0..2 with pixel row r = hr - dy), so every fragment is fetched from LDS once; dy fragments of the last
+    // three pixel rows stay in a 4-deep register ring.  Next step's fragment is requested before this step's MFMAs.
+    bf16x8 Af[2], Bf[4];
+    auto loadA = [&](auto Sc) {
+      constexpr int st = decltype(Sc)::value, hr = st / 3, dx = st % 3;
+      const bf16_t* ad = sX + (hr * HWd + tr_px + dx) * RSX + mi * 32 + tr_ch;
+      Af[st & 1] = tr_frag(ad, ad + 4 * RSX);
+    };
+    auto loadB = [&](auto Rc) {
+      constexpr int r = decltype(Rc)::value;
       const bf16_t* bd = sD + (r * 16 + tr_px) * RSD + ni * 32 + tr_ch;
-      const bf16x8 bfr = tr_frag(bd, bd + 4 * RSD);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const bf16_t* ad = sX + ((r + tap / 3) * HWd + tr_px + tap % 3) * RSX + mi * 32 + tr_ch;
-        const bf16x8 afr = tr_frag(ad, ad + 4 * RSX);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
-      }
-    }
+      Bf[r & 3] = tr_frag(bd, bd + 4 * RSD);
+    };
+    loadB(std::integral_constant<int, 0>{});
+    loadA(std::integral_constant<int, 0>{});
+    static_for<0, 3 * (PTH + 2)>([&](auto S) {
+      constexpr int st = decltype(S)::value, hr = st / 3, dx = st % 3;
+      if constexpr (st + 1 < 3 * (PTH + 2)) loadA(std::integral_constant<int, st + 1>{});
+      if constexpr (dx == 0 && hr + 1 < PTH) loadB(std::integral_constant<int, hr + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 3>([&](auto DY) {
+        constexpr int dy = decltype(DY)::value, r = hr - dy;
+        if constexpr (r >= 0 && r < PTH)
+          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+      });
+    });
   }
   const int co = co0 + ni * 32 + l31;
   if (co < P.Cout) {
