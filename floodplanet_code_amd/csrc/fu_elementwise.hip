@@ -811,8 +811,11 @@ __global__ void k_head_fwd(const T* __restrict__ y, const float* __restrict__ a,
     float acc[HEAD_MAX_CLS];
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-      float d = z[0] * wv[k][0] + z[1] * wv[k][1] + z[2] * wv[k][2] + z[3] * wv[k][3];
-      for (int off = LPP >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      float d = 0.f;
+      if (k < ncls) {   // wave-uniform: unused classes cost no cross-lane traffic
+        d = z[0] * wv[k][0] + z[1] * wv[k][1] + z[2] * wv[k][2] + z[3] * wv[k][3];
+        for (int off = LPP >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      }
       acc[k] = d;
     }
     if (valid && lane_in == 0) {
@@ -1134,7 +1137,7 @@ int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int
 // ------------------------------------------------------------------------------------------------
 // head backward: G[p][c] = sum_k dl[p][k] w[k][c];  dW[k][c] = sum_p dl[p][k] z[p][c];  db[k] = sum_p dl[p][k]
 // ------------------------------------------------------------------------------------------------
-static constexpr int HB_BLOCKS = 512;
+static constexpr int HB_BLOCKS = 2048;
 
 template <typename T>
 __global__ void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y, const float* __restrict__ a,
