@@ -157,10 +157,20 @@ def main():
             best = {"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value}
     peak = PEAK_TFLOPS[args.dtype]
     roof = None
+    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of this same command; counters cannot be read live): profiles/r1_pmc_<dtype>.json
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r1_pmc_{args.dtype}.json")) as fh:
+            pm = json.load(fh)
+        if best and best["kernel"] in pm and B == 16 and S == 256 and Cc == 8:
+            traffic = pm[best["kernel"]]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if best:
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": best["kernel"], "achieved": round(achieved, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches": best["launches"], "avg_launch_ms": round(best["ms"] / best["launches"], 4),
                 "avg_launch_gflop": round(best["flops"] / best["launches"] / 1e9, 3),
                 "whole_step_frac_of_conv_roofline": round(value / world * train_fl / 1e12 / peak, 4)}
