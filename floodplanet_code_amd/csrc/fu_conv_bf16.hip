@@ -390,7 +390,7 @@ static int launch_cfg(BConvP& P, hipStream_t s) {
   return 0;
 }
 
-int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64, 1 = 256x128, 2 = 256x32
+int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64 tile, 2 = 256x32 tile
 
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
                         int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
@@ -405,18 +405,15 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   // tile choice (all tiles are 16x16 = 256 output pixels).  Measured on MI355X (profiles/): two 4-wave workgroups
   // per CU (256x64 tile, 80 KB LDS) overlap one group's LDS staging with the other's MFMA block and beat the
   // 8-wave 256x128 tile (higher FLOP/byte but lock-step phases) on every layer that yields >= 512 workgroups;
-  // 256x32 keeps the small deep levels at >= 256 workgroups.
+  // 256x32 keeps the small deep levels at >= 256 workgroups.  (Also tried and measured slower, hence not built: the
+  // 8-wave 256x128 tile with single or double-buffered 16-channel LDS stages, 810-900 TF where this one reaches 870-960.)
   const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
   int cfg;
   if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512) cfg = 0;
   else cfg = 2;
-  static int env_cfg = -2;
-  if (env_cfg == -2) { const char* e = getenv("FU_BF16_CFG"); env_cfg = e ? atoi(e) : -1; }
-  if (env_cfg >= 0 && !(env_cfg == 1 && P.N < 128)) cfg = env_cfg;
-  if (g_bf16_force_cfg >= 0) cfg = g_bf16_force_cfg;
+  if (g_bf16_force_cfg == 0 || g_bf16_force_cfg == 2) cfg = g_bf16_force_cfg;
   int st;
-  if (cfg == 1) st = launch_cfg<4, 2, 2>(P, s);
-  else if (cfg == 0) st = launch_cfg<4, 1, 2>(P, s);
+  if (cfg == 0) st = launch_cfg<4, 1, 2>(P, s);
   else st = launch_cfg<4, 1, 1>(P, s);
   if (n_stat_tiles) *n_stat_tiles = P.nPix;
   return st;
