@@ -430,7 +430,7 @@ struct BWgP {
 
 // Two transposing reads -> one MFMA fragment.  NOTE (hipcc / ROCm 7.2): the v4i16 form of the builtin followed by
 // per-element bit casts to __bf16 is miscompiled (element 0 is replicated); the v4bf16 form + shufflevector is correct
-// (checked on hardware, scratch/tr_probe3.hip).
+// (checked on hardware, tools/probes/tr_probe3.hip).
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
