@@ -1,5 +1,5 @@
 import sys, torch
-import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from conftest import case_inputs, load_golden, is_dead_bias
 from floodplanet_code_amd.unet import HipUNet
 from oracle import unet_oracle as O
