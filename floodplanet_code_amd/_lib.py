@@ -68,6 +68,8 @@ SIGNATURES = {
     "fu_adam_step": (_i, [_p, _f, _f, _f, _f, _i64, _f, _p]),
     "fu_adam_state": (_i, [_p, C.POINTER(_p), C.POINTER(_p)]),
     "fu_zero_grads": (_i, [_p, _p]),
+    "fu_stitch_add": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fu_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "fu_augment": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _p]),
     "fu_workspace_bytes": (_i64, [_p]),
     "fu_flops_per_tile": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

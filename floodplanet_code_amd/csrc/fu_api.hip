@@ -875,6 +875,28 @@ int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* tota
   return FU_OK;
 }
 
+int fu_stitch_add(fu_ctx* c, int sample, float* canvas, float* weight, int canvas_h, int canvas_w, int h0, int w0,
+                  int hE, int wE, fu_stream stream) {
+  FU_REQUIRE(c && canvas && weight, "fu_stitch_add: null argument");
+  FU_REQUIRE(c->last_batch > 0 && sample >= 0 && sample < c->last_batch, "fu_stitch_add: sample %d not in the last batch",
+             sample);
+  const int H = c->cfg.height, W = c->cfg.width;
+  const int dh = hE - h0, dw = wE - w0;
+  FU_REQUIRE(h0 >= 0 && w0 >= 0 && dh >= 0 && dw >= 0 && hE <= canvas_h && wE <= canvas_w && dh <= H && dw <= W,
+             "fu_stitch_add: crop [%d:%d, %d:%d] does not fit canvas %dx%d / tile %dx%d", h0, hE, w0, wE, canvas_h,
+             canvas_w, H, W);
+  if (dh == 0 || dw == 0) return FU_OK;
+  const float* lg = c->logits + (int64_t)sample * H * W * c->cfg.n_classes;
+  return launch_stitch_add(lg, c->cfg.n_classes, W, canvas, weight, canvas_w, h0, w0, dh, dw, (hipStream_t)stream);
+}
+
+int fu_stitch_finalize(float* canvas, const float* weight, int n_classes, int canvas_h, int canvas_w,
+                       int64_t* argmax_out, fu_stream stream) {
+  FU_REQUIRE(canvas && weight && n_classes >= 1 && n_classes <= HEAD_MAX_CLS, "fu_stitch_finalize: bad argument");
+  return launch_stitch_finalize(canvas, weight, n_classes, (int64_t)canvas_h * canvas_w, argmax_out,
+                                (hipStream_t)stream);
+}
+
 int fu_augment(const float* image, const int64_t* target, float* image_out, int64_t* target_out, const int32_t* flags,
                const float* angles_deg, int B, int C, int H, int W, int64_t target_fill, fu_stream stream) {
   FU_REQUIRE(image && image_out && flags && angles_deg, "fu_augment: null argument");

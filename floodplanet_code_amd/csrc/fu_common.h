@@ -225,6 +225,10 @@ int64_t head_bwd_partial_elems(int C, int ncls);
 int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
                     int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s);
 
+int launch_stitch_add(const float* logits_nhwc, int ncls, int cropW, float* canvas, float* weight, int canvasW, int h0,
+                      int w0, int dh, int dw, hipStream_t s);
+int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t npix, int64_t* argmax_out,
+                           hipStream_t s);
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -1280,6 +1280,64 @@ int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Inference stitching (utils/utils_image.py:410-494, predict.py:329-347): softmax of a crop's logits is added into an
+// overlap-averaging canvas, canvas[h0:hE, w0:wE, :] += p[:dh, :dw, :], weight += 1; finalisation divides by
+// (weight + 1e-5) and emits the argmax map.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_stitch_add(const float* __restrict__ logits_nhwc, int ncls, int cropW, float* __restrict__ canvas,
+                             float* __restrict__ weight, int canvasW, int h0, int w0, int dh, int dw) {
+  const int64_t total = (int64_t)dh * dw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % dw), y = (int)(idx / dw);
+    const float* z = logits_nhwc + ((int64_t)y * cropW + x) * ncls;
+    float m = -INFINITY, e[HEAD_MAX_CLS], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) m = fmaxf(m, z[k]);
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) { e[k] = k < ncls ? expf(z[k] - m) : 0.f; se += e[k]; }
+    const float inv = 1.f / se;
+    const int64_t o = (int64_t)(h0 + y) * canvasW + (w0 + x);
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) canvas[o * ncls + k] += e[k] * inv;
+    weight[o] += 1.f;
+  }
+}
+
+__global__ void k_stitch_finalize(float* __restrict__ canvas, const float* __restrict__ weight, int ncls,
+                                  int64_t npix, int64_t* __restrict__ argmax_out) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const float inv = 1.f / (weight[p] + 1e-5f);
+    float best = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+      if (k < ncls) {
+        const float v = canvas[p * ncls + k] * inv;
+        canvas[p * ncls + k] = v;
+        if (v > best) { best = v; am = k; }
+      }
+    }
+    if (argmax_out) argmax_out[p] = am;
+  }
+}
+
+int launch_stitch_add(const float* logits_nhwc, int ncls, int cropW, float* canvas, float* weight, int canvasW, int h0,
+                      int w0, int dh, int dw, hipStream_t s) {
+  hipLaunchKernelGGL(k_stitch_add, dim3(grid_for((int64_t)dh * dw, 256, 2048)), dim3(256), 0, s, logits_nhwc, ncls,
+                     cropW, canvas, weight, canvasW, h0, w0, dh, dw);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t npix, int64_t* argmax_out,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_stitch_finalize, dim3(grid_for(npix, 256, 2048)), dim3(256), 0, s, canvas, weight, ncls, npix,
+                     argmax_out);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor update order; water_seg_model.py:200)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

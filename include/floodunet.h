@@ -148,6 +148,15 @@ enum { FU_AUG_HFLIP = 1, FU_AUG_VFLIP = 2, FU_AUG_ROTATE = 4 };
 int fu_augment(const float* image, const int64_t* target, float* image_out, int64_t* target_out, const int32_t* flags,
                const float* angles_deg, int B, int C, int H, int W, int64_t target_fill, fu_stream stream);
 
+/* ---- inference stitching (ImageStitcher_v2, utils/utils_image.py:410-494) ------------- */
+/* canvas[h0:hE, w0:wE, :] += softmax(logits of sample `sample` of the last fu_forward)[:hE-h0, :wE-w0, :];
+ * weight[h0:hE, w0:wE] += 1.  canvas: fp32 [canvas_h, canvas_w, n_classes], weight: fp32 [canvas_h, canvas_w]. */
+int fu_stitch_add(fu_ctx* ctx, int sample, float* canvas, float* weight, int canvas_h, int canvas_w, int h0, int w0,
+                  int hE, int wE, fu_stream stream);
+/* canvas /= (weight + 1e-5) in place (ImageStitcher_v2._combine_images); argmax_out: optional int64 [canvas_h, canvas_w] */
+int fu_stitch_finalize(float* canvas, const float* weight, int n_classes, int canvas_h, int canvas_w,
+                       int64_t* argmax_out, fu_stream stream);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 int64_t fu_workspace_bytes(const fu_ctx* ctx);
 /* algorithmic conv FLOPs of one tile: forward, and forward+backward */

@@ -354,3 +354,30 @@ def test_minimal_trainer_runs_the_lightning_protocol(tmp_path):
     with torch.no_grad():
         out = m2(batch)
     assert out.shape == (2, 3, 64, 64) and torch.isfinite(out).all()
+
+
+def test_gpu_stitching_matches_numpy_canvas():
+    """Overlap-average stitching (ImageStitcher_v2 arithmetic) on the logits resident after an eval forward."""
+    from floodplanet_code_amd.stitch import GpuImageStitcher
+    st = O.make_state(4, 3, 8, True, seed=1)
+    net = HipUNet(4, 3, base_channels=8)
+    net.load_state_dict(st)
+    net.to(DEV).eval()
+    big = torch.rand(1, 4, 96, 112, generator=torch.Generator().manual_seed(0))
+    crops = [(0, 0), (0, 48), (32, 0), (32, 48)]            # 64x64 crops, stride (32, 48): overlaps both ways
+    x = torch.stack([big[0, :, h:h + 64, w:w + 64] for h, w in crops]).to(DEV)
+    with torch.no_grad():
+        logits = net(x)
+    stitch = GpuImageStitcher(net, DEV)
+    canvas = np.zeros((96, 112, 3)); weight = np.zeros((96, 112))
+    probs = torch.softmax(logits, 1).permute(0, 2, 3, 1).cpu().numpy()
+    for i, (h, w) in enumerate(crops):
+        hE, wE = min(h + 64, 96), min(w + 64, 112)
+        stitch.add_image(i, "img", (h, w, hE, wE), 96, 112)
+        canvas[h:hE, w:wE] += probs[i, :hE - h, :wE - w]
+        weight[h:hE, w:wE] += 1
+    got, am = stitch.combine("img")
+    torch.cuda.synchronize()
+    ref = canvas / (weight[..., None] + 1e-5)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6)
+    assert (am.cpu().numpy() == ref.argmax(-1)).mean() > 0.999
