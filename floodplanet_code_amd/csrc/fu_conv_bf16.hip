@@ -406,7 +406,9 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   // per CU (256x64 tile, 80 KB LDS) overlap one group's LDS staging with the other's MFMA block and beat the
   // 8-wave 256x128 tile (higher FLOP/byte but lock-step phases) on every layer that yields >= 512 workgroups;
   // 256x32 keeps the small deep levels at >= 256 workgroups.  (Also tried and measured slower, hence not built: the
-  // 8-wave 256x128 tile with single or double-buffered 16-channel LDS stages, 810-900 TF where this one reaches 870-960.)
+  // 8-wave 256x128 tile with single or double-buffered 16-channel LDS stages (810-900 TF where this one reaches 870-1040)
+  // and a warp-specialised 4 loader + 4 compute wave version with two LDS stages (790-915 TF).  Removing the per-chunk
+  // staging altogether lets the same MFMA loop run at 1200-1430 TF, so staging costs ~30 % on the deep layers.)
   const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
   int cfg;
   if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512) cfg = 0;
