@@ -176,7 +176,7 @@ def main():
                 "whole_step_frac_of_conv_roofline": round(value / world * train_fl / 1e12 / peak, 4)}
 
     out = {
-        "metric": "training tiles/sec (256x256x8ch UNet)", "value": round(value, 3), "unit": "tiles/s",
+        "metric": f"training tiles/sec ({S}x{S}x{Cc}ch UNet)", "value": round(value, 3), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"UNet depth-4 (17.27M params), {Cc}-band {S}x{S} tiles, batch {B}/GPU, "

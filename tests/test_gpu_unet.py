@@ -381,3 +381,43 @@ def test_gpu_stitching_matches_numpy_canvas():
     ref = canvas / (weight[..., None] + 1e-5)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6)
     assert (am.cpu().numpy() == ref.argmax(-1)).mean() > 0.999
+
+
+def test_baseline_config4_512_tiles_with_dem_channel_bf16_dice():
+    """BASELINE configs[3]: 512x512 tiles, 8 bands + DEM (9 channels through the early-fusion concat), reduced
+    precision conv math with fp32 loss reductions (here bf16 + the BCE/Dice extension)."""
+    from floodplanet_code_amd.fit import SyntheticTiles
+    torch.manual_seed(0)
+    m = build_model("ef_model", {"ms_image": 8, "dem": 1}, 3, 1e-3, log_image_iter=50, to_rgb_fcn=None,
+                    ignore_index=-100, precision="bf16").to(DEV)
+    assert m.model.n_channels == 9
+    batch = next(iter(SyntheticTiles(1, 2, {"ms_image": 8, "dem": 1}, 512, 512, DEV, seed=3)))
+    m._set_model_to_train()
+    x = m._gather_input(batch)
+    assert x.shape == (2, 9, 512, 512)
+    losses = []
+    for step in range(1, 5):
+        loss = m.model.train_step(x, batch["target"], -100, kind="bce_dice", dice_weight=1.0)
+        m.model.adam_step(1e-3, step)
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_baseline_config5_12_channel_stack_with_gpu_augmentation():
+    """BASELINE configs[4]: 12-channel stacked input, augmentation on the GPU before the HIP training step."""
+    from floodplanet_code_amd import augment
+    from floodplanet_code_amd.fit import SyntheticTiles
+    torch.manual_seed(0)
+    net = HipUNet(12, 3, precision="bf16").to(DEV).train()
+    batch = next(iter(SyntheticTiles(1, 4, {"ms_image": 12}, 256, 256, DEV, seed=5)))
+    rng = np.random.RandomState(0)
+    losses = []
+    for step in range(1, 5):
+        flags, angles = augment.sample_transforms(4, rng=rng)
+        x, t = augment.apply(batch["image"], batch["target"], flags, angles, target_fill=0)
+        loss = net.train_step(x, t, 0)
+        net.adam_step(1e-3, step)
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0]
