@@ -421,3 +421,19 @@ def test_baseline_config5_12_channel_stack_with_gpu_augmentation():
         losses.append(loss.item())
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0]
+
+
+def test_convtranspose_variant_bf16_tracks_fp32():
+    """bilinear=False in bf16: same stated tolerance as the bilinear net against the reference fixture."""
+    meta, z = load_golden("f_convT_c4_32")
+    batch, st = case_inputs(meta)
+    net = HipUNet(meta["n_in"], 3, bilinear=False, base_channels=64, precision="bf16")
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    loss, logits = net.loss(batch["image"].to(DEV), batch["target"].to(DEV), 0, return_logits=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    d = logits.detach().cpu().numpy() - z["logits1"]
+    assert np.abs(d).max() <= 0.25 and np.sqrt((d ** 2).mean()) <= 0.05
+    assert abs(loss.item() - z["loss1"].item()) <= 0.03
+    assert torch.isfinite(net.flat_grads()).all()
