@@ -108,6 +108,8 @@ def main():
     import ctypes as C
 
     precision = "fp32" if args.dtype == "f32" else "bf16"
+    if os.environ.get("FU_BENCH_GENERAL_CONV") == "1":   # A/B knob: general bf16 conv kernel instead of the fast one
+        _lib.load().fu_test_force_general_conv(1)
     torch.manual_seed(0)
     net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
     trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank)

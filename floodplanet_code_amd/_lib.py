@@ -74,6 +74,7 @@ SIGNATURES = {
     "fu_workspace_bytes": (_i64, [_p]),
     "fu_flops_per_tile": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fu_profile_enable": (_i, [_p, _i]),
+    "fu_test_force_general_conv": (None, [_i]),
     "fu_profile_read": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                              C.POINTER(C.c_char_p)]),
     "fu_elem_size": (_i, [_i]),

@@ -13,34 +13,13 @@
 //       fragments are fetched with the hardware transposing read ds_read_b64_tr_b16.  9 accumulator tiles per
 //       wave (one per tap); split-K slabs in fp32, reduced by the shared fixed-order kernel.
 #include "fu_common.h"
+#include "fu_conv_bf16.h"
 
 #include <stdlib.h>
 #include <type_traits>
 
 namespace fu {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-// compile-time loop: every array index below is a constant expression, so the staging registers are never
-// demoted to scratch (runtime-indexed private arrays are -- cdna guide rule 20)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-#define FU_LAUNCH_CHECK()                                                       \
-  do {                                                                          \
-    hipError_t _e = hipGetLastError();                                          \
-    if (_e != hipSuccess) {                                                     \
-      set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
-      return 2;                                                                 \
-    }                                                                           \
-  } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // weight packing (bf16): OIHW fp32 -> wf[tap][co][ci_pad] and wd[8-tap][ci_pad][co]
@@ -73,13 +52,6 @@ int launch_pack_conv3x3_bf16(const float* w_oihw, int Cout, int cin_real, int ci
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
-struct BConvP {
-  const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0;
-  const bf16_t* wpk;   // [9][N][Cin]
-  const float* bias;
-  bf16_t* dst0; bf16_t* dst1; float* stats;
-  int C0, C1, Cin, N, D0, D1, B, H, W, tilesX, tilesY, nPix, nCo;
-};
 
 template <int WM, int WN, int NTW>
 struct BCfg {
@@ -391,6 +363,8 @@ static int launch_cfg(BConvP& P, hipStream_t s) {
 }
 
 int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64 tile, 2 = 256x32 tile
+int g_bf16_force_general = 0;   // testing hook (fu_test_force_general_conv): skip the aligned-shape fast kernel
+unsigned long long* g_conv_dbg = nullptr;
 
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
                         int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
@@ -399,6 +373,7 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.wpk = wpk; P.bias = bias; P.dst0 = dst0; P.dst1 = dst1; P.stats = stats;
   P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.N = D0 + D1; P.D0 = D0; P.D1 = D1;
   P.B = B; P.H = H; P.W = W;
+  P.dbg = g_conv_dbg;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
   FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);
@@ -409,6 +384,11 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   // 8-wave 256x128 tile with single or double-buffered 16-channel LDS stages (810-900 TF where this one reaches 870-1040)
   // and a warp-specialised 4 loader + 4 compute wave version with two LDS stages (790-915 TF).  Removing the per-chunk
   // staging altogether lets the same MFMA loop run at 1200-1430 TF, so staging costs ~30 % on the deep layers.)
+  if (!g_bf16_force_general && conv3x3_bf16_fast_eligible(P)) {
+    const int st = launch_conv3x3_bf16_fast(P, s);
+    if (n_stat_tiles) *n_stat_tiles = P.nPix;
+    return st;
+  }
   const int64_t t256 = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16);
   int cfg;
   if (P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512) cfg = 0;
@@ -677,3 +657,6 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
 }
 
 }  // namespace fu
+
+extern "C" void fu_test_force_general_conv(int on) { fu::g_bf16_force_general = on; }
+extern "C" void fu_debug_set_conv_stamps(void* p) { fu::g_conv_dbg = (unsigned long long*)p; }

@@ -1,0 +1,431 @@
+// bf16 3x3 convolution, forward / dgrad, aligned-shape fast path for gfx950.
+//
+// Same implicit GEMM, LDS image and MFMA schedule as k_conv3x3_bf16 (fu_conv_bf16.hip), rewritten around one
+// measurement: on the 64..128-channel layers the general kernel issues ~900 VALU/SALU instructions per 32-channel
+// chunk and ~1100 in its epilogue against 72 MFMAs per chunk (2300 MFMA cycles), i.e. the waves are VALU-issue bound
+// (s_memtime stamps, tools/stamp_test.py: prologue 6100 + epilogue 6200 cycles around a 10200-cycle main loop).  This
+// kernel keeps every per-load / per-store quantity in a register that is computed once per tile:
+//   * global loads   : uniform (SGPR) chunk base + one 32-bit byte offset per staging slot, no per-chunk address math;
+//   * BN+ReLU        : v_pk_fma_f32 on channel pairs, v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the packed pair;
+//   * zero padding   : only border tiles / ragged chunks take the masked variant (workgroup-uniform branch);
+//   * epilogue       : packed statistics (v_pk_add/fma_f32), convert first and transpose the 4x4 lane quad on PACKED
+//                      pairs (2 DPP + 2 v_perm + 1 DPP + 3 selects per 4 registers), stores from a uniform base + a
+//                      per-lane byte offset computed once, immediate offsets for the second channel tile.
+// Shapes it takes (conv3x3_bf16_fast_eligible): a second source only if C0 % 32 == 0, a second destination only if
+// D0 % BN == 0, every tensor < 2 GiB.  Everything else (and only that) runs on the general kernel.
+#include "fu_conv_bf16.h"
+
+namespace fu {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int NTW>
+struct FCfg {
+  static constexpr int NT = 256, TW = 16, TH = 16, BN = 32 * NTW, KC = 32, KCP = 40;
+  static constexpr int HWd = TW + 2, NHP = (TH + 2) * HWd;
+  static constexpr int A_UNITS = NHP * 4;                              // 16-byte units (8 channels) per chunk
+  static constexpr int A_ITERS = (A_UNITS + NT - 1) / NT, A_FULL = A_UNITS / NT, A_REM = A_UNITS % NT;
+  static constexpr int W_UNITS = 9 * BN * 4;
+  static constexpr int W_ITERS = (W_UNITS + NT - 1) / NT, W_FULL = W_UNITS / NT, W_REM = W_UNITS % NT;
+  static constexpr int ROWS_PER_IT = NT / 4;                           // LDS rows (pixels / weight rows) per iteration
+  static constexpr int TAPS_PER_IT = ROWS_PER_IT / BN;                 // 1 (BN = 64) or 2 (BN = 32)
+  static constexpr int AB_FLOATS = 2 * 1024;                           // BN scale / shift of source 0
+  static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2 + AB_FLOATS * 4;
+  static_assert(W_REM % 64 == 0, "the ragged weight iteration must be wave-uniform");
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32
+}
+
+// relu(a * x + b) on the two bf16 channels of one dword; one rounding to bf16
+__device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
+  f32x2 x;
+  x.x = __uint_as_float(v << 16);
+  x.y = __uint_as_float(v & 0xffff0000u);
+  x = x * a + b;                                                             // v_pk_fma_f32
+  const s16x2 h = __builtin_bit_cast(s16x2, pack_bf16x2(x));
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: bf16 sign test = relu
+}
+
+// n / d for n * d < 2^32 with rcp = floor(2^32 / d) + 1 (0 encodes d == 1)
+__device__ __forceinline__ int fast_div(int n, int d, unsigned rcp) {
+  return rcp ? (int)__umulhi((unsigned)n, rcp) : n;
+}
+static unsigned host_rcp(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)d + 1); }
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
+  using Cfg = FCfg<NTW>;
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, KC = Cfg::KC, KCP = Cfg::KCP, NT = Cfg::NT;
+  constexpr int HWd = Cfg::HWd, NHP = Cfg::NHP, A_ITERS = Cfg::A_ITERS, W_ITERS = Cfg::W_ITERS;
+  constexpr int RPI = Cfg::ROWS_PER_IT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);            // [NHP][KCP]
+  bf16_t* sW = sA + NHP * KCP;                                 // [9][BN][KCP]
+  float* sAB = reinterpret_cast<float*>(sW + 9 * BN * KCP);    // [2][1024] BN scale / shift of source 0
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = 64-pixel slice of the tile (uniform)
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // tile decode: three divisions by launch constants, as multiply-high with host-made reciprocals (a hardware integer
+  // division is ~35 instructions through the float unit, and all of this sits in front of the first load)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int coT = fast_div(logical, P.nPix, P.rcp_nPix);
+  const int pixT = logical - coT * P.nPix;
+  const int t2 = fast_div(pixT, P.tilesX, P.rcp_tilesX);
+  const int tx = pixT - t2 * P.tilesX;
+  const int bb = fast_div(t2, P.tilesY, P.rcp_tilesY);
+  const int ty = t2 - bb * P.tilesY;
+  const int x0 = tx * TW, y0 = ty * TH, n0 = coT * BN;
+  const bool has_bn = P.a0 != nullptr;
+  // tiles whose halo leaves the image need zero padding; the others skip the masks altogether
+  const bool border = !(y0 >= 1 && y0 + TH + 1 <= P.H && x0 >= 1 && x0 + TW + 1 <= P.W);
+
+  // ---- staging slots.  Slot `it` of thread t is 16-byte unit u = t + 256 it: halo pixel u >> 2, channel octet t & 3.
+  //      a_off = byte offset of that unit inside the CURRENT source at channel 0 (recomputed once, at the switch to
+  //      the second source); out-of-image pixels load the nearest image pixel and are zeroed when written to LDS.
+  const int aq = tid & 3;
+  unsigned a_off[A_ITERS];
+  unsigned a_ok = 0;
+  auto setup_a = [&](int Cs) {
+    a_ok = 0;
+    static_for<0, A_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int hp = (tid >> 2) + it * RPI;
+      const int hy = (hp * 3641) >> 16;                          // hp / 18 (exact for hp < 65536)
+      const int hx = hp - hy * HWd;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);   // clamped: always a valid address
+      const bool ok = (it < Cfg::A_FULL || hp < NHP) && iy == cy && ix == cx;
+      a_ok |= ok ? (1u << it) : 0u;
+      a_off[it] = (unsigned)((bb * P.H + cy) * P.W + cx) * (unsigned)(Cs * 2) + 16u * aq;
+    });
+  };
+  setup_a(P.C0);
+  // weights [tap][n][Cin]: row r = (t >> 2) + 64 it  ->  tap = r / BN, n = n0 + r % BN; the per-iteration part of the
+  // address is uniform.  Rows past N load row 0 (their output columns are never stored).
+  const int wrow = tid >> 2;
+  const int wco = wrow & (BN - 1), wtsub = wrow / BN;
+  const bool w_ok = n0 + wco < P.N;
+  const unsigned w_off = (w_ok ? (unsigned)((wtsub * P.N + n0 + wco) * P.Cin) * 2u : 0u) + 16u * aq;
+  const unsigned w_step = (unsigned)(Cfg::TAPS_PER_IT * P.N * P.Cin) * 2u;
+
+  uint4 ra[A_ITERS];
+  uint4 rw[W_ITERS];
+
+  auto load_chunk = [&](int k0) {
+    const bool s1 = P.src1 != nullptr && k0 >= P.C0;           // uniform: C0 % 32 == 0 when there is a second source
+    const char* ab = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
+                        : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
+    const char* wb = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
+    // ragged last chunk (Cin % 32 != 0): octets past Cin load offset 0 and are zeroed on the A side
+    const unsigned cm = (k0 + 8 * aq < P.Cin) ? 0xffffffffu : 0u;
+    static_for<0, A_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      ra[it] = *reinterpret_cast<const uint4*>(ab + (a_off[it] & cm));
+    });
+    const unsigned wo = w_off & cm;
+    static_for<0, W_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      if (it < Cfg::W_FULL || wm < Cfg::W_REM / 64)
+        rw[it] = *reinterpret_cast<const uint4*>(wb + (wo + (unsigned)it * w_step));
+    });
+  };
+
+  auto store_chunk = [&](int k0, auto Mc) {
+    constexpr bool MASKED = decltype(Mc)::value;
+    const bool bn = has_bn && k0 < P.C0;                        // uniform
+    unsigned km = 0;
+    if constexpr (MASKED) km = (k0 + 8 * aq < P.Cin) ? a_ok : 0u;
+    // coefficient reads are unconditional (stale LDS is harmless when the chunk has no BN): a conditional
+    // definition would turn the registers into a scratch array
+    const int cc = (bn ? k0 : 0) + 8 * aq;                      // < 1024 + 32: inside sAB even on a ragged chunk
+    const float4 a0 = *reinterpret_cast<const float4*>(sAB + cc);
+    const float4 a1 = *reinterpret_cast<const float4*>(sAB + cc + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sAB + 1024 + cc);
+    const float4 b1 = *reinterpret_cast<const float4*>(sAB + 1024 + cc + 4);
+    const f32x2 ca0 = {a0.x, a0.y}, ca1 = {a0.z, a0.w}, ca2 = {a1.x, a1.y}, ca3 = {a1.z, a1.w};
+    const f32x2 cb0 = {b0.x, b0.y}, cb1 = {b0.z, b0.w}, cb2 = {b1.x, b1.y}, cb3 = {b1.z, b1.w};
+    static_for<0, A_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      if (it < Cfg::A_FULL || tid < Cfg::A_REM) {
+        unsigned x = ra[it].x, y = ra[it].y, z = ra[it].z, w = ra[it].w;
+        if (bn) {
+          x = bn_relu_pair(x, ca0, cb0); y = bn_relu_pair(y, ca1, cb1);
+          z = bn_relu_pair(z, ca2, cb2); w = bn_relu_pair(w, ca3, cb3);
+        }
+        if constexpr (MASKED) {
+          const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)km, it, 1);   // bit it -> 0 / 0xffffffff
+          x &= m; y &= m; z &= m; w &= m;
+        }
+        *reinterpret_cast<uint4*>(sA + ((tid >> 2) + it * RPI) * KCP + 8 * aq) = make_uint4(x, y, z, w);
+      }
+    });
+    static_for<0, W_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      if (it < Cfg::W_FULL || wm < Cfg::W_REM / 64)
+        // component-wise: a whole-struct copy becomes a memcpy from the array and keeps it in scratch
+        *reinterpret_cast<uint4*>(sW + (wrow + it * RPI) * KCP + 8 * aq) =
+            make_uint4(rw[it].x, rw[it].y, rw[it].z, rw[it].w);
+    });
+  };
+
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment base offsets (bf16 elements).  m-tile = 2 image rows x 16 columns; lanes 16..31 (second row) take their
+  // columns ROTATED by HWd mod 16 so that the 16 lanes of every ds_read_b128 group hit 16 distinct bank slots.
+  int aoff[2], boff[NTW];
+  const int mrow = l31 >> 4;
+  const int mcol = mrow ? ((l31 - 16 - (HWd & 15)) & 15) : l31;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wm * 2 + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) boff[nt] = (nt * 32 + l31) * KCP + 8 * lh;
+
+  const int nChunks = (P.Cin + KC - 1) / KC;
+#ifdef FU_CONV_STAMPS
+  unsigned long long T0 = __builtin_amdgcn_s_memtime(), T1 = 0, T2 = 0;
+#endif
+  load_chunk(0);                         // the first chunk's loads go out before anything else
+  float biasv[NTW];                      // bias is fetched here: a load in the epilogue would expose a full memory
+#pragma unroll                           // latency (and its vmcnt(0) would also wait for the stores before it)
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = n0 + nt * 32 + l31;
+    biasv[nt] = (P.bias != nullptr && n < P.N) ? P.bias[n] : 0.f;
+  }
+  if (has_bn) {                          // BN coefficients of source 0 -> LDS (behind the loads above)
+    for (int c = tid; c < P.C0; c += NT) { sAB[c] = P.a0[c]; sAB[1024 + c] = P.b0[c]; }
+  }
+#ifdef FU_CONV_STAMPS
+  unsigned long long Sbar = 0, Swait = 0, Sstore = 0, Smfma = 0, tp = T0;
+#endif
+  for (int ch = 0; ch < nChunks; ++ch) {
+    const int k0 = ch * KC;
+    __syncthreads();            // previous chunk's fragment reads are done (and sAB is visible on the first pass)
+#ifdef FU_CONV_STAMPS
+    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
+    if (border || k0 + KC > P.Cin) store_chunk(k0, std::true_type{});
+    else store_chunk(k0, std::false_type{});
+    __syncthreads();
+#ifdef FU_CONV_STAMPS
+    const unsigned long long tb = __builtin_amdgcn_s_memtime();
+    Sbar += ta - tp; Swait += tw - ta; Sstore += tb - tw;
+    if (ch == 0) T1 = tb;
+#endif
+    if (ch + 1 < nChunks) {
+      if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // next chunk starts the second source
+      load_chunk(k0 + KC);                                      // raw loads stay in flight under the MFMA block
+    }
+    // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
+    // s+1 are requested from LDS before the MFMAs of step s are issued.
+    bf16x8 af[2][2], bfr[2][NTW];
+    auto load_frags = [&](auto Sc, auto Bc) {
+      constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
+      constexpr int tap = st >> 1, ks = st & 1;
+      constexpr int toff = ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+        bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+    };
+    load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<0, 18>([&](auto S) {
+      constexpr int st = decltype(S)::value, buf = st & 1;
+      if constexpr (st + 1 < 18) {
+        load_frags(std::integral_constant<int, st + 1>{}, std::integral_constant<int, buf ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
+    });
+#ifdef FU_CONV_STAMPS
+    tp = __builtin_amdgcn_s_memtime();
+    Smfma += tp - tb;
+#endif
+  }
+#ifdef FU_CONV_STAMPS
+  T2 = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // Accumulator layout: lane = channel (l31), registers = 16 pixels.  Values are converted to bf16 pairs first
+  // (2 pixels of one channel per dword), then the 4x4 (pixel x channel) block of every lane quad is transposed on the
+  // packed data: xor-1 DPP + v_perm (per-lane byte selector), xor-2 DPP + selects.  Afterwards lane j of a quad owns
+  // channels 4q..4q+3 of pixel j: one 8-byte store, 8 pixels x 64 contiguous bytes per wave instruction.
+  const int qj = lane & 3;
+  const bool q_even = !(lane & 1), q_lo = qj < 2;
+  const unsigned sel1 = q_even ? 0x05040100u : 0x03020706u;     // even: (own.lo, recv.lo)  odd: (recv.hi, own.hi)
+  const bool to0 = n0 < P.D0;                                   // uniform: D0 % BN == 0 with two destinations
+  char* dbase = reinterpret_cast<char*>(to0 ? P.dst0 + n0 : P.dst1 + (n0 - P.D0));
+  const int dstride = to0 ? P.D0 : P.D1;
+  float ssum[NTW], ssq[NTW];
+
+  auto epilogue = [&](auto Fc, auto Bc) {
+    constexpr bool FULL = decltype(Fc)::value, BIAS = decltype(Bc)::value;
+    unsigned sb[2][4];     // byte offset of the store of (mt, g) from dbase
+    unsigned sok = 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int p = qj + 8 * g + 4 * lh;
+        const int oy = y0 + (wm * 2 + mt) * 2 + (g >> 1);
+        const int ox = x0 + ((g >> 1) ? ((p - 16 - (HWd & 15)) & 15) : p);
+        sb[mt][g] = ((unsigned)((bb * P.H + oy) * P.W + ox) * (unsigned)dstride + (unsigned)(l31 & ~3)) * 2u;
+        if constexpr (!FULL) sok |= (oy < P.H && ox < P.W) ? (1u << (mt * 4 + g)) : 0u;
+      }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = n0 + nt * 32 + l31;
+      const bool nok = n < P.N;
+      const f32x2 bias2 = {biasv[nt], biasv[nt]};
+      const bool nqok = (n & ~3) < P.N;
+      f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x2 a01 = {acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1]};
+          f32x2 a23 = {acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+          if constexpr (FULL) {
+            s2 += a01; s2 += a23;
+            q2 = a01 * a01 + q2; q2 = a23 * a23 + q2;
+          } else {
+            const int oy = y0 + (wm * 2 + mt) * 2 + (g >> 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int p = k + 8 * g + 4 * lh;                   // MFMA row -> pixel (second row rotated, see aoff)
+              const int ox = x0 + ((g >> 1) ? ((p - 16 - (HWd & 15)) & 15) : p);
+              const float a = acc[mt][nt][4 * g + k];
+              if (nok && oy < P.H && ox < P.W) { s2.x += a; q2.x = fmaf(a, a, q2.x); }
+            }
+          }
+          if constexpr (BIAS) { a01 += bias2; a23 += bias2; }
+          const unsigned p01 = pack_bf16x2(a01), p23 = pack_bf16x2(a23);
+          const unsigned r01 = (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xF, 0xF, true);   // quad xor 1
+          const unsigned r23 = (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xF, 0xF, true);
+          const unsigned A = __builtin_amdgcn_perm(r01, p01, sel1);     // pixel (qj & 1),     channel pair
+          const unsigned Bq = __builtin_amdgcn_perm(r23, p23, sel1);    // pixel 2 + (qj & 1), channel pair
+          const unsigned send = q_lo ? Bq : A;
+          const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);  // quad xor 2
+          uint2 o;
+          o.x = q_lo ? A : recv;
+          o.y = q_lo ? recv : Bq;
+          if (FULL || (nqok && ((sok >> (mt * 4 + g)) & 1u)))
+            *reinterpret_cast<uint2*>(dbase + sb[mt][g] + nt * 64) = o;
+        }
+      }
+      ssum[nt] = s2.x + s2.y;
+      ssq[nt] = q2.x + q2.y;
+    }
+  };
+  const bool full = (y0 + TH <= P.H) && (x0 + TW <= P.W) && (n0 + BN <= P.N);   // workgroup-uniform
+  if (full) {
+    if (P.bias) epilogue(std::true_type{}, std::true_type{});
+    else epilogue(std::true_type{}, std::false_type{});
+  } else {
+    if (P.bias) epilogue(std::false_type{}, std::true_type{});
+    else epilogue(std::false_type{}, std::false_type{});
+  }
+
+#ifdef FU_CONV_STAMPS
+  const unsigned long long T2b = __builtin_amdgcn_s_memtime();
+#endif
+  if (P.stats) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4][BN][2]
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      ssum[nt] += __shfl_xor(ssum[nt], 32, 64);
+      ssq[nt] += __shfl_xor(ssq[nt], 32, 64);
+    }
+    __syncthreads();
+    if (lh == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int cn = nt * 32 + l31;
+        red[(wm * BN + cn) * 2 + 0] = ssum[nt];
+        red[(wm * BN + cn) * 2 + 1] = ssq[nt];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < P.N) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { s += red[(m * BN + tid) * 2 + 0]; q += red[(m * BN + tid) * 2 + 1]; }
+      float* o = P.stats + ((int64_t)pixT * P.N + n0 + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+#ifdef FU_CONV_STAMPS
+  const unsigned long long T2c = __builtin_amdgcn_s_memtime();
+  if (P.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = P.dbg + (size_t)blockIdx.x * 10;
+    d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = Sbar; d[5] = Swait; d[6] = Sstore; d[7] = Smfma; d[8] = T2b; d[9] = T2c;
+  }
+#endif
+}
+
+bool conv3x3_bf16_fast_eligible(const BConvP& P) {
+  const int64_t px = (int64_t)P.B * P.H * P.W;
+  const int64_t lim = (int64_t)1 << 31;
+  if (P.src1 && (P.C0 % 32) != 0) return false;
+  if (P.dst1 && (P.D0 % 32) != 0) return false;
+  if (P.C0 > 1024 || (P.C0 % 8) || (P.C1 % 8) || (P.N % 4)) return false;
+  if (px * P.C0 * 2 >= lim || px * P.C1 * 2 >= lim || px * P.D0 * 2 >= lim || px * P.D1 * 2 >= lim) return false;
+  if ((int64_t)9 * P.N * P.Cin * 2 >= lim) return false;
+  return true;
+}
+
+template <int NTW>
+static int launch_fast_cfg(BConvP& P, hipStream_t s) {
+  using Cfg = FCfg<NTW>;
+  P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
+  P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
+  P.rcp_nPix = host_rcp(P.nPix); P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
+  FU_REQUIRE((int64_t)P.nPix * P.nCo * P.nPix < ((int64_t)1 << 32), "conv3x3_bf16_fast: grid too large (%d x %d)",
+             P.nPix, P.nCo);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_fast<NTW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    attr_set = true;
+  }
+  const ProfSlot ps = g_prof_slot;
+  g_prof_slot = ProfSlot();
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// Tile choice (all tiles are 16x16 = 256 output pixels): 64 output channels per workgroup when that still yields
+// >= 512 workgroups (two per CU), else 32.
+int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
+  const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
+  const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
+  return wide ? launch_fast_cfg<2>(P, s) : launch_fast_cfg<1>(P, s);
+}
+
+}  // namespace fu

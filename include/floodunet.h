@@ -174,6 +174,10 @@ int fu_profile_enable(fu_ctx* ctx, int enable);
 int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
                     const char** kernel_name);
 
+/* Testing hook: on != 0 makes every bf16 3x3 convolution (forward / dgrad) run on the general kernel even when the
+ * shape is eligible for the aligned-shape fast kernel, so that the parity tests can cover both.  Process-wide. */
+void fu_test_force_general_conv(int on);
+
 /* ---- single operators (per-op parity tests; NHWC device buffers of the context's precision) -- */
 /* element size of the activation type for `precision` */
 int fu_elem_size(int precision);

@@ -171,6 +171,9 @@ BF_SHAPES = [
     (2, 8, 0, 64, 224, 224, False),  # 256x64 tiles, single ragged K chunk
     (2, 32, 0, 128, 192, 192, True), # 256x128 tiles
     (3, 32, 32, 136, 50, 38, True),  # odd sizes
+    (2, 64, 32, 96, 48, 80, True),   # interior + border tiles, two sources (switch after 2 chunks), 64 + 32 channel tiles
+    (1, 96, 0, 32, 16, 16, False),   # one tile, narrow (32-channel) workgroups
+    (2, 128, 64, 64, 40, 24, True),  # second destination at a 64-channel boundary (dgrad: D0 = 128)
 ]
 
 
@@ -186,8 +189,17 @@ def nchw_bf(x):
     return x.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
+@pytest.fixture(params=["auto", "general"])
+def conv_path(request):
+    """bf16 forward/dgrad have an aligned-shape fast kernel and a general one: run every shape on both."""
+    lib = _lib.load()
+    lib.fu_test_force_general_conv(1 if request.param == "general" else 0)
+    yield request.param
+    lib.fu_test_force_general_conv(0)
+
+
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_forward_and_stats(shape):
+def test_conv3x3_bf16_forward_and_stats(shape, conv_path):
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape)
@@ -214,7 +226,7 @@ def test_conv3x3_bf16_forward_and_stats(shape):
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_dgrad(shape):
+def test_conv3x3_bf16_dgrad(shape, conv_path):
     B, C0, C1, Cout, H, W, _ = shape
     lib = _lib.load()
     g = torch.Generator().manual_seed(1)
