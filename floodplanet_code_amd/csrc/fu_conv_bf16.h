@@ -29,6 +29,34 @@ __device__ __forceinline__ void static_for(F&& f) {
     }                                                                           \
   } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32
+}
+
+// relu(a * x + b) on the two bf16 channels of one dword; one rounding to bf16
+__device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
+  f32x2 x;
+  x.x = __uint_as_float(v << 16);
+  x.y = __uint_as_float(v & 0xffff0000u);
+  x = x * a + b;                                                             // v_pk_fma_f32
+  const s16x2 h = __builtin_bit_cast(s16x2, pack_bf16x2(x));
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: bf16 sign test = relu
+}
+
+// n / d for n * d < 2^32 with rcp = floor(2^32 / d) + 1 (0 encodes d == 1)
+__device__ __forceinline__ int fast_div(int n, int d, unsigned rcp) {
+  return rcp ? (int)__umulhi((unsigned)n, rcp) : n;
+}
+static inline unsigned host_rcp(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)d + 1); }
+
+#endif
+
 // forward / dgrad launch parameters (see launch_conv3x3_bf16)
 struct BConvP {
   const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0;
@@ -43,5 +71,8 @@ struct BConvP {
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
 bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
+// (experimental/fu_conv_bf16_pipe.hip holds a persistent, software-pipelined variant with this launcher; it is not
+// built: measured 8-14 % slower than the fast kernel)
+int launch_conv3x3_bf16_pipe(BConvP& P, hipStream_t s);
 
 }  // namespace fu

@@ -15,11 +15,11 @@
 // D0 % BN == 0, every tensor < 2 GiB.  Everything else (and only that) runs on the general kernel.
 #include "fu_conv_bf16.h"
 
-namespace fu {
+#ifndef FU_FAST_DBG
+#define FU_FAST_DBG 0   // experiments: 4 = epilogue without global stores
+#endif
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
+namespace fu {
 
 template <int NTW>
 struct FCfg {
@@ -35,27 +35,6 @@ struct FCfg {
   static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2 + AB_FLOATS * 4;
   static_assert(W_REM % 64 == 0, "the ragged weight iteration must be wave-uniform");
 };
-
-__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32
-}
-
-// relu(a * x + b) on the two bf16 channels of one dword; one rounding to bf16
-__device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
-  f32x2 x;
-  x.x = __uint_as_float(v << 16);
-  x.y = __uint_as_float(v & 0xffff0000u);
-  x = x * a + b;                                                             // v_pk_fma_f32
-  const s16x2 h = __builtin_bit_cast(s16x2, pack_bf16x2(x));
-  const s16x2 z = {0, 0};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: bf16 sign test = relu
-}
-
-// n / d for n * d < 2^32 with rcp = floor(2^32 / d) + 1 (0 encodes d == 1)
-__device__ __forceinline__ int fast_div(int n, int d, unsigned rcp) {
-  return rcp ? (int)__umulhi((unsigned)n, rcp) : n;
-}
-static unsigned host_rcp(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)d + 1); }
 
 template <int NTW>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
@@ -329,8 +308,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
           uint2 o;
           o.x = q_lo ? A : recv;
           o.y = q_lo ? recv : Bq;
+#if FU_FAST_DBG == 4
+          asm volatile("" ::"v"(o.x), "v"(o.y));
+#else
           if (FULL || (nqok && ((sok >> (mt * 4 + g)) & 1u)))
             *reinterpret_cast<uint2*>(dbase + sb[mt][g] + nt * 64) = o;
+#endif
         }
       }
       ssum[nt] = s2.x + s2.y;

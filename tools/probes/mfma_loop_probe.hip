@@ -1,0 +1,74 @@
+// How fast can one wave per SIMD run the conv's inner loop?  18 k-steps x 4 v_mfma_f32_32x32x16_bf16 with the same LDS
+// fragment reads (ds_read_b128, 80-byte rows) as k_conv3x3_bf16_*; variants: MFMA only / + fragment reads at
+// prefetch distance 1 or 2 k-steps / 1 or 2 waves per SIMD.  Prints cycles per k-step (ideal: 4 x 32 = 128).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include <type_traits>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+constexpr int KCP = 40, HWd = 18, NHP = 324, BN = 64, STAGE = (NHP + 9 * BN) * KCP;
+
+template <int MODE, int DIST>   // MODE 0: MFMA only, 1: with LDS reads
+__global__ __launch_bounds__(512) void k_loop(unsigned long long* out, float* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sS = reinterpret_cast<unsigned short*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) & 3, l31 = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < STAGE; i += blockDim.x) sS[i] = 0x3c00 + (i & 63);
+  __syncthreads();
+  int aoff[2], boff[2];
+  const int mrow = l31 >> 4, mcol = mrow ? ((l31 - 16 - 2) & 15) : l31;
+  for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wm * 2 + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
+  for (int nt = 0; nt < 2; ++nt) boff[nt] = NHP * KCP + (nt * 32 + l31) * KCP + 8 * lh;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 af[3][2], bfr[3][2];
+  auto load_frag = [&](auto Sc, auto Rc) {
+    constexpr int st = decltype(Sc)::value, r = decltype(Rc)::value, buf = st % 3, tap = st >> 1, ks = st & 1;
+    if constexpr (r < 2) af[buf][r] = *reinterpret_cast<const bf16x8*>(sS + aoff[r] + ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16);
+    else bfr[buf][r - 2] = *reinterpret_cast<const bf16x8*>(sS + boff[r - 2] + tap * BN * KCP + ks * 16);
+  };
+  static_for<0, 3>([&](auto Sc) { static_for<0, 4>([&](auto Rc) { load_frag(Sc, Rc); }); });
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (MODE == 1) static_for<0, DIST>([&](auto Sc) { static_for<0, 4>([&](auto Rc) { load_frag(Sc, Rc); }); });
+    static_for<0, 72>([&](auto Mc) {
+      constexpr int m = decltype(Mc)::value, st = m / 4, j = m % 4, mt = j / 2, nt = j % 2;
+      if constexpr (MODE == 1 && st + DIST < 18) load_frag(std::integral_constant<int, st + DIST>{}, std::integral_constant<int, j>{});
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st % 3][mt], bfr[st % 3][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[0] = s;
+  if (lane == 0) out[blockIdx.x * (blockDim.x / 64) + (tid >> 6)] = t1 - t0;
+}
+
+template <int MODE, int DIST>
+void run(const char* name, int threads, unsigned long long* out, float* sink) {
+  const int iters = 50, nw = 256 * threads / 64;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop<MODE, DIST>), hipFuncAttributeMaxDynamicSharedMemorySize, STAGE * 2);
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k_loop<MODE, DIST>), dim3(256), dim3(threads), STAGE * 2, 0, out, sink, iters);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(nw);
+  hipMemcpy(h.data(), out, nw * 8, hipMemcpyDeviceToHost);
+  double s = 0; for (auto v : h) s += v;
+  printf("%-44s %d waves/SIMD: %.1f ticks per k-step (4 MFMA)\n", name, threads / 256, s / nw / iters / 18.0);
+}
+int main() {
+  unsigned long long* out; float* sink;
+  hipMalloc(&out, 1 << 20); hipMalloc(&sink, 64);
+  for (int threads : {256, 512}) {
+    run<0, 1>("MFMA only", threads, out, sink);
+    run<1, 1>("MFMA + ds_read_b128 frags, distance 1", threads, out, sink);
+    run<1, 2>("MFMA + ds_read_b128 frags, distance 2", threads, out, sink);
+  }
+  return 0;
+}
