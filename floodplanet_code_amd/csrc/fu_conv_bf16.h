@@ -43,17 +43,11 @@ __device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
   f32x2 x;
   x.x = __uint_as_float(v << 16);
   x.y = __uint_as_float(v & 0xffff0000u);
-  x = x * a + b;                                                             // v_pk_fma_f32
+  x = __builtin_elementwise_fma(a, x, b);                                    // v_pk_fma_f32 (= bn_act_fused per lane)
   const s16x2 h = __builtin_bit_cast(s16x2, pack_bf16x2(x));
   const s16x2 z = {0, 0};
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: bf16 sign test = relu
 }
-
-// n / d for n * d < 2^32 with rcp = floor(2^32 / d) + 1 (0 encodes d == 1)
-__device__ __forceinline__ int fast_div(int n, int d, unsigned rcp) {
-  return rcp ? (int)__umulhi((unsigned)n, rcp) : n;
-}
-static inline unsigned host_rcp(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)d + 1); }
 
 #endif
 

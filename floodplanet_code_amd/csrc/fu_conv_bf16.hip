@@ -72,10 +72,10 @@ __device__ __forceinline__ uint4 bn_relu_pack8(uint4 v, const float4& a0, const 
   x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
   x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
   x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
-  x[0] = fmaxf(a0.x * x[0] + b0.x, 0.f); x[1] = fmaxf(a0.y * x[1] + b0.y, 0.f);
-  x[2] = fmaxf(a0.z * x[2] + b0.z, 0.f); x[3] = fmaxf(a0.w * x[3] + b0.w, 0.f);
-  x[4] = fmaxf(a1.x * x[4] + b1.x, 0.f); x[5] = fmaxf(a1.y * x[5] + b1.y, 0.f);
-  x[6] = fmaxf(a1.z * x[6] + b1.z, 0.f); x[7] = fmaxf(a1.w * x[7] + b1.w, 0.f);
+  x[0] = bn_act_fused(a0.x, x[0], b0.x); x[1] = bn_act_fused(a0.y, x[1], b0.y);
+  x[2] = bn_act_fused(a0.z, x[2], b0.z); x[3] = bn_act_fused(a0.w, x[3], b0.w);
+  x[4] = bn_act_fused(a1.x, x[4], b1.x); x[5] = bn_act_fused(a1.y, x[5], b1.y);
+  x[6] = bn_act_fused(a1.z, x[6], b1.z); x[7] = bn_act_fused(a1.w, x[7], b1.w);
   uint4 o;
   o.x = (unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16);
   o.y = (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16);

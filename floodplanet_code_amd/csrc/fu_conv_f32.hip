@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_f32(ConvP P) {
         if (from0) {
           v = *reinterpret_cast<const float4*>(P.src0 + a_pix[it] * P.C0 + c);
           if (has_bn) {
-            v.x = fmaxf(av.x * v.x + bv.x, 0.f);
-            v.y = fmaxf(av.y * v.y + bv.y, 0.f);
-            v.z = fmaxf(av.z * v.z + bv.z, 0.f);
-            v.w = fmaxf(av.w * v.w + bv.w, 0.f);
+            v.x = bn_act(av.x, v.x, bv.x);
+            v.y = bn_act(av.y, v.y, bv.y);
+            v.z = bn_act(av.z, v.z, bv.z);
+            v.w = bn_act(av.w, v.w, bv.w);
           }
         } else {
           v = *reinterpret_cast<const float4*>(P.src1 + a_pix[it] * P.C1 + (c - P.C0));
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(WgP P) {
           if (from0) {
             v = *reinterpret_cast<const float4*>(P.src0 + pix * P.C0 + cX);
             if (has_bn) {
-              v.x = fmaxf(av.x * v.x + bv.x, 0.f);
-              v.y = fmaxf(av.y * v.y + bv.y, 0.f);
-              v.z = fmaxf(av.z * v.z + bv.z, 0.f);
-              v.w = fmaxf(av.w * v.w + bv.w, 0.f);
+              v.x = bn_act(av.x, v.x, bv.x);
+              v.y = bn_act(av.y, v.y, bv.y);
+              v.z = bn_act(av.z, v.z, bv.z);
+              v.w = bn_act(av.w, v.w, bv.w);
             }
           } else {
             v = *reinterpret_cast<const float4*>(P.src1 + pix * P.C1 + (cX - P.C0));

@@ -250,7 +250,7 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y
       ElemIO<T>::load4(y + p * C + cv * 4, yv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float z = av[j] * yv[j] + bv[j];
+        const float z = bn_act_pre(av[j], yv[j], bv[j]);
         const float gm = z > 0.f ? gv[j] : 0.f;
         s1[j] += gm;
         s2[j] += gm * ((yv[j] - mv[j]) * iv[j]);
@@ -319,7 +319,7 @@ __global__ void k_bn_bwd_apply(T* __restrict__ g, const T* __restrict__ y, int C
       ElemIO<T>::load4(y + p * C + cv * 4, yv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float z = av[j] * yv[j] + bv[j];
+        const float z = bn_act_pre(av[j], yv[j], bv[j]);
         const float gm = z > 0.f ? gv[j] : 0.f;
         const float xh = (yv[j] - mv[j]) * iv[j];
         o[j] = av[j] * (gm - c1[j] - xh * c2[j]);
@@ -389,91 +389,119 @@ __device__ __forceinline__ void load_act4(const T* p, const float (&av)[4], cons
   ElemIO<T>::load4(p, z);
   if (bn) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) z[j] = fmaxf(av[j] * z[j] + bv[j], 0.f);
+    for (int j = 0; j < 4; ++j) z[j] = bn_act(av[j], z[j], bv[j]);
+  }
+}
+
+// Elementwise NHWC kernels below share one indexing scheme: grid = (items of one output row / 256, rows, batch), one
+// 16-byte channel vector (VecIO: 4 fp32 / 8 bf16) per thread, 32-bit index math.  (The first versions decoded a flat
+// 64-bit index with four 64-bit divisions per 8-byte vector and ran 2-5x off the HBM roofline on index math alone.)
+template <typename T, int V>
+__device__ __forceinline__ void load_act(const T* p, const float (&av)[V], const float (&bv)[V], bool bn, float (&z)[V]) {
+  VecIO<T>::load(p, z);
+  if (bn) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) z[j] = bn_act(av[j], z[j], bv[j]);
+  }
+}
+template <int V>
+__device__ __forceinline__ void load_coef(const float* a, const float* b, int c0, float (&av)[V], float (&bv)[V]) {
+#pragma unroll
+  for (int j = 0; j < V; j += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(a + c0 + j);
+    const float4 y = *reinterpret_cast<const float4*>(b + c0 + j);
+    av[j] = x.x; av[j + 1] = x.y; av[j + 2] = x.z; av[j + 3] = x.w;
+    bv[j] = y.x; bv[j + 1] = y.y; bv[j + 2] = y.z; bv[j + 3] = y.w;
   }
 }
 
 template <typename T>
-__global__ void k_maxpool2(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
-                           T* __restrict__ dst, int H, int W, int C, int Ho, int Wo, int64_t total) {
-  const int CV = C >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    int64_t r = idx / CV;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int64_t bb = r / Ho;
-    float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-    const bool bn = a != nullptr;
-    if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
-    const T* base = src + ((bb * H + oy * 2) * W + ox * 2) * (int64_t)C + cv * 4;
-    float z00[4], z01[4], z10[4], z11[4], o[4];
-    load_act4<T>(base, av, bv, bn, z00);
-    load_act4<T>(base + C, av, bv, bn, z01);
-    load_act4<T>(base + (int64_t)W * C, av, bv, bn, z10);
-    load_act4<T>(base + (int64_t)W * C + C, av, bv, bn, z11);
+__global__ __launch_bounds__(256) void k_maxpool2(const T* __restrict__ src, const float* __restrict__ a,
+                                                  const float* __restrict__ b, T* __restrict__ dst, int H, int W, int C,
+                                                  int Ho, int Wo, int CV, unsigned rcpCV) {
+  constexpr int V = VecIO<T>::V;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= Wo * CV) return;
+  const int ox = fast_div(item, CV, rcpCV), cv = item - ox * CV;
+  const int oy = blockIdx.y, bb = blockIdx.z;
+  float av[V], bv[V];
+  const bool bn = a != nullptr;
+  if (bn) load_coef<V>(a, b, cv * V, av, bv);
+  const T* base = src + ((size_t)(bb * H + oy * 2) * W + ox * 2) * C + cv * V;
+  float z00[V], z01[V], z10[V], z11[V], o[V];
+  load_act<T, V>(base, av, bv, bn, z00);
+  load_act<T, V>(base + C, av, bv, bn, z01);
+  load_act<T, V>(base + (size_t)W * C, av, bv, bn, z10);
+  load_act<T, V>(base + (size_t)W * C + C, av, bv, bn, z11);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(z00[j], z01[j]), fmaxf(z10[j], z11[j]));
-    ElemIO<T>::store4(dst + idx * 4, o);
-  }
+  for (int j = 0; j < V; ++j) o[j] = fmaxf(fmaxf(z00[j], z01[j]), fmaxf(z10[j], z11[j]));
+  VecIO<T>::store(dst + ((size_t)(bb * Ho + oy) * Wo + ox) * C + cv * V, o);
 }
 
 // g_src[first argmax of the window] += g_dst   (ties -> first in row-major order, as ATen's max_pool2d)
 template <typename T>
-__global__ void k_maxpool2_bwd(const T* __restrict__ gdst, const T* __restrict__ ysrc, const float* __restrict__ a,
-                               const float* __restrict__ b, T* __restrict__ gsrc, int H, int W, int C, int Ho, int Wo,
-                               int64_t total) {
-  const int CV = C >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    int64_t r = idx / CV;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int64_t bb = r / Ho;
-    float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-    const bool bn = a != nullptr;
-    if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
-    const int64_t off = ((bb * H + oy * 2) * W + ox * 2) * (int64_t)C + cv * 4;
-    const int64_t offs[4] = {off, off + C, off + (int64_t)W * C, off + (int64_t)W * C + C};
-    float z[4][4], gv[4];
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(const T* __restrict__ gdst, const T* __restrict__ ysrc,
+                                                      const float* __restrict__ a, const float* __restrict__ b,
+                                                      T* __restrict__ gsrc, int H, int W, int C, int Ho, int Wo, int CV,
+                                                      unsigned rcpCV) {
+  constexpr int V = VecIO<T>::V;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= Wo * CV) return;
+  const int ox = fast_div(item, CV, rcpCV), cv = item - ox * CV;
+  const int oy = blockIdx.y, bb = blockIdx.z;
+  float av[V], bv[V];
+  const bool bn = a != nullptr;
+  if (bn) load_coef<V>(a, b, cv * V, av, bv);
+  const size_t off = ((size_t)(bb * H + oy * 2) * W + ox * 2) * C + cv * V;
+  const size_t offs[4] = {off, off + C, off + (size_t)W * C, off + (size_t)W * C + C};
+  float z[4][V], gv[V];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) load_act4<T>(ysrc + offs[q], av, bv, bn, z[q]);
-    ElemIO<T>::load4(gdst + idx * 4, gv);
-    int arg[4];
+  for (int q = 0; q < 4; ++q) load_act<T, V>(ysrc + offs[q], av, bv, bn, z[q]);
+  VecIO<T>::load(gdst + ((size_t)(bb * Ho + oy) * Wo + ox) * C + cv * V, gv);
+  int arg[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int am = 0;
-      float m = z[0][j];
+  for (int j = 0; j < V; ++j) {
+    int am = 0;
+    float m = z[0][j];
 #pragma unroll
-      for (int q = 1; q < 4; ++q)
-        if (z[q][j] > m) { m = z[q][j]; am = q; }
-      arg[j] = am;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float cur[4];
-      ElemIO<T>::load4(gsrc + offs[q], cur);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cur[j] += (arg[j] == q) ? gv[j] : 0.f;
-      ElemIO<T>::store4(gsrc + offs[q], cur);
-    }
+    for (int q = 1; q < 4; ++q)
+      if (z[q][j] > m) { m = z[q][j]; am = q; }
+    arg[j] = am;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float cur[V];
+    VecIO<T>::load(gsrc + offs[q], cur);
+#pragma unroll
+    for (int j = 0; j < V; ++j) cur[j] += (arg[j] == q) ? gv[j] : 0.f;
+    VecIO<T>::store(gsrc + offs[q], cur);
+  }
+}
+
+// launch geometry of the row kernels above
+template <typename T>
+static bool row_grid(int C, int items_w, int rows, int B, dim3* grid, int* CV, unsigned* rcp) {
+  constexpr int V = 16 / (int)sizeof(T);
+  if (C % V != 0 || rows > 65535 || B > 65535) return false;
+  *CV = C / V;
+  *rcp = host_rcp(*CV);
+  *grid = dim3(ceil_div(items_w * *CV, 256), rows, B);
+  return true;
 }
 
 int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                     hipStream_t s) {
-  FU_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0");
   const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-  const int g = grid_for(total, 256);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_maxpool2<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, Ho,
-                       Wo, total);
-  else
-    hipLaunchKernelGGL(k_maxpool2<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
-                       Ho, Wo, total);
+  dim3 g; int CV; unsigned rcp;
+  if (p == PREC_F32) {
+    FU_REQUIRE(row_grid<float>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2<float>, g, dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, Ho, Wo, CV,
+                       rcp);
+  } else {
+    FU_REQUIRE(row_grid<bf16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C, Ho, Wo,
+                       CV, rcp);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -481,14 +509,16 @@ int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, voi
 int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const float* a, const float* b, void* g_src,
                         int B, int H, int W, int C, hipStream_t s) {
   const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-  const int g = grid_for(total, 256);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_maxpool2_bwd<float>, dim3(g), dim3(256), 0, s, (const float*)g_dst, (const float*)y_src, a,
-                       b, (float*)g_src, H, W, C, Ho, Wo, total);
-  else
-    hipLaunchKernelGGL(k_maxpool2_bwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)g_dst, (const bf16_t*)y_src, a,
-                       b, (bf16_t*)g_src, H, W, C, Ho, Wo, total);
+  dim3 g; int CV; unsigned rcp;
+  if (p == PREC_F32) {
+    FU_REQUIRE(row_grid<float>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (const float*)y_src, a, b,
+                       (float*)g_src, H, W, C, Ho, Wo, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<bf16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (const bf16_t*)y_src, a, b,
+                       (bf16_t*)g_src, H, W, C, Ho, Wo, CV, rcp);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -497,85 +527,88 @@ int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const floa
 // bilinear x2 (align_corners=True) of relu(a*y+b), zero-padded to outH x outW (F.pad of unet.py:57-62)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_upsample2(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
-                            T* __restrict__ dst, int H, int W, int C, int outH, int outW, int py0, int px0,
-                            UpTables t, int64_t total) {
-  const int CV = C >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    int64_t r = idx / CV;
-    const int ox = (int)(r % outW); r /= outW;
-    const int oy = (int)(r % outH);
-    const int64_t bb = r / outH;
-    float o[4] = {0, 0, 0, 0};
-    const int uy = oy - py0, ux = ox - px0;
-    if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W) {
-      float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-      const bool bn = a != nullptr;
-      if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
-      const int y0 = t.y_i0[uy], y1 = t.y_i1[uy];
-      const int x0 = t.x_i0[ux], x1 = t.x_i1[ux];
-      const float wy1 = t.y_w1[uy], wx1 = t.x_w1[ux];
-      const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-      const T* base = src + bb * H * (int64_t)W * C + cv * 4;
-      float z00[4], z01[4], z10[4], z11[4];
-      load_act4<T>(base + ((int64_t)y0 * W + x0) * C, av, bv, bn, z00);
-      load_act4<T>(base + ((int64_t)y0 * W + x1) * C, av, bv, bn, z01);
-      load_act4<T>(base + ((int64_t)y1 * W + x0) * C, av, bv, bn, z10);
-      load_act4<T>(base + ((int64_t)y1 * W + x1) * C, av, bv, bn, z11);
+__global__ __launch_bounds__(256) void k_upsample2(const T* __restrict__ src, const float* __restrict__ a,
+                                                   const float* __restrict__ b, T* __restrict__ dst, int H, int W, int C,
+                                                   int outH, int outW, int py0, int px0, UpTables t, int CV,
+                                                   unsigned rcpCV) {
+  constexpr int V = VecIO<T>::V;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= outW * CV) return;
+  const int ox = fast_div(item, CV, rcpCV), cv = item - ox * CV;
+  const int oy = blockIdx.y, bb = blockIdx.z;
+  float o[V];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        o[j] = wy0 * (wx0 * z00[j] + wx1 * z01[j]) + wy1 * (wx0 * z10[j] + wx1 * z11[j]);
-    }
-    ElemIO<T>::store4(dst + idx * 4, o);
+  for (int j = 0; j < V; ++j) o[j] = 0.f;
+  const int uy = oy - py0, ux = ox - px0;                       // uy is block-uniform: its table entries are scalar loads
+  if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W) {
+    float av[V], bv[V];
+    const bool bn = a != nullptr;
+    if (bn) load_coef<V>(a, b, cv * V, av, bv);
+    // source index and weight as ATen computes them (area_pixel_compute_scale<float>, align_corners=True): the same
+    // float expressions as the host tables of the backward pass (fu_api.hip build_axis), evaluated here so that no
+    // load depends on a table load
+    const float sy = t.scale_y * (float)uy, sx = t.scale_x * (float)ux;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float wy1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+    const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+    const T* base = src + (size_t)bb * H * W * C + cv * V;
+    float z00[V], z01[V], z10[V], z11[V];
+    load_act<T, V>(base + ((size_t)y0 * W + x0) * C, av, bv, bn, z00);
+    load_act<T, V>(base + ((size_t)y0 * W + x1) * C, av, bv, bn, z01);
+    load_act<T, V>(base + ((size_t)y1 * W + x0) * C, av, bv, bn, z10);
+    load_act<T, V>(base + ((size_t)y1 * W + x1) * C, av, bv, bn, z11);
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      o[j] = wy0 * (wx0 * z00[j] + wx1 * z01[j]) + wy1 * (wx0 * z10[j] + wx1 * z11[j]);
   }
+  VecIO<T>::store(dst + ((size_t)(bb * outH + oy) * outW + ox) * C + cv * V, o);
 }
 
 template <typename T>
-__global__ void k_upsample2_bwd(const T* __restrict__ gdst, T* __restrict__ gsrc, int H, int W, int C, int outH,
-                                int outW, int py0, int px0, UpTables t, int64_t total) {
-  const int CV = C >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(idx % CV);
-    int64_t r = idx / CV;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int64_t bb = r / H;
-    float acc[4] = {0, 0, 0, 0};
-    const T* base = gdst + bb * outH * (int64_t)outW * C + cv * 4;
-    for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
-      const int oy = t.yb_o[iy * UP_BWD_MAX + jy];
-      if (oy < 0) break;
-      const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
-      for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
-        const int ox = t.xb_o[ix * UP_BWD_MAX + jx];
-        if (ox < 0) break;
-        const float w = wy * t.xb_w[ix * UP_BWD_MAX + jx];
-        float gv[4];
-        ElemIO<T>::load4(base + ((int64_t)(oy + py0) * outW + (ox + px0)) * C, gv);
+__global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gdst, T* __restrict__ gsrc, int H, int W,
+                                                       int C, int outH, int outW, int py0, int px0, UpTables t, int CV,
+                                                       unsigned rcpCV) {
+  constexpr int V = VecIO<T>::V;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= W * CV) return;
+  const int ix = fast_div(item, CV, rcpCV), cv = item - ix * CV;
+  const int iy = blockIdx.y, bb = blockIdx.z;
+  float acc[V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += w * gv[j];
-      }
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const T* base = gdst + (size_t)bb * outH * outW * C + cv * V;
+  for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
+    const int oy = t.yb_o[iy * UP_BWD_MAX + jy];                // block-uniform
+    if (oy < 0) break;
+    const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
+    for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
+      const int ox = t.xb_o[ix * UP_BWD_MAX + jx];
+      if (ox < 0) break;
+      const float w = wy * t.xb_w[ix * UP_BWD_MAX + jx];
+      float gv[V];
+      VecIO<T>::load(base + ((size_t)(oy + py0) * outW + (ox + px0)) * C, gv);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += w * gv[j];
     }
-    ElemIO<T>::store4(gsrc + idx * 4, acc);
   }
+  VecIO<T>::store(gsrc + ((size_t)(bb * H + iy) * W + ix) * C + cv * V, acc);
 }
 
 int launch_upsample2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                      int outH, int outW, const UpTables& t, hipStream_t s) {
-  FU_REQUIRE(C % 4 == 0, "upsample: C %% 4 != 0");
   FU_REQUIRE(outH >= 2 * H && outW >= 2 * W, "upsample: target smaller than 2x source");
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
-  const int64_t total = (int64_t)B * outH * outW * (C / 4);
-  const int g = grid_for(total, 256);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_upsample2<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C,
-                       outH, outW, py0, px0, t, total);
-  else
-    hipLaunchKernelGGL(k_upsample2<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
-                       outH, outW, py0, px0, t, total);
+  dim3 g; int CV; unsigned rcp;
+  if (p == PREC_F32) {
+    FU_REQUIRE(row_grid<float>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
+    hipLaunchKernelGGL(k_upsample2<float>, g, dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, outH, outW,
+                       py0, px0, t, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<bf16_t>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
+    hipLaunchKernelGGL(k_upsample2<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -583,14 +616,16 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
 int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
                          const UpTables& t, hipStream_t s) {
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
-  const int64_t total = (int64_t)B * H * W * (C / 4);
-  const int g = grid_for(total, 256);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_upsample2_bwd<float>, dim3(g), dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C,
-                       outH, outW, py0, px0, t, total);
-  else
-    hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W,
-                       C, outH, outW, py0, px0, t, total);
+  dim3 g; int CV; unsigned rcp;
+  if (p == PREC_F32) {
+    FU_REQUIRE(row_grid<float>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<bf16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -786,48 +821,85 @@ int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hi
 // head: logits[p][k] = bias[k] + sum_c relu(a*y+b)[p][c] * w[k][c]      (OutConv, unet.py:74-77)
 // LPP = C/4 lanes cooperate on one pixel (16 for C = 64); partial dot products meet through wave shuffles.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void k_head_fwd(const T* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
-                           const float* __restrict__ w, const float* __restrict__ bias, int C, int ncls, int64_t npix,
-                           int HW, float* __restrict__ logits_nhwc, float* __restrict__ logits_nchw) {
-  const int LPP = C >> 2;  // power of two <= 16
-  const int lane_in = threadIdx.x % LPP;
-  const int ppb = blockDim.x / LPP;  // pixels per block iteration
-  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-  const bool bn = a != nullptr;
-  if (bn) { ElemIO<float>::load4(a + lane_in * 4, av); ElemIO<float>::load4(b + lane_in * 4, bv); }
-  float wv[HEAD_MAX_CLS][4];
-#pragma unroll
-  for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-    if (k < ncls) ElemIO<float>::load4(w + k * C + lane_in * 4, wv[k]);
-    else wv[k][0] = wv[k][1] = wv[k][2] = wv[k][3] = 0.f;
+// sum over the LPP (power of two <= 16) consecutive lanes of a group; the result is valid in the LAST lane of the
+// group.  DPP only: quad_perm for xor 1 / 2, row_shr for the quad-to-quad steps (a __shfl_xor is a ds_bpermute).
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_sel) {
+  int r;
+  const int x = __float_as_int(v);
+  switch (ctrl_sel) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); break;   // row_shr:4
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); break;  // row_shr:8
   }
-  const int64_t niter = ceil_div64(npix, ppb);
-  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
-    const int64_t p = it * ppb + threadIdx.x / LPP;
-    const bool valid = p < npix;
-    float z[4] = {0, 0, 0, 0};
-    if (valid) load_act4<T>(y + p * C + lane_in * 4, av, bv, bn, z);
-    float acc[HEAD_MAX_CLS];
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float group_sum_last(float v, int LPP) {
+  // largest distance first: the same association as the xor-shuffle tree this replaces (bit-identical fp32 logits)
+  if (LPP >= 16) v = dpp_add(v, 3);
+  if (LPP >= 8) v = dpp_add(v, 2);
+  if (LPP >= 4) v = dpp_add(v, 1);
+  if (LPP >= 2) v = dpp_add(v, 0);
+  return v;
+}
+
+// NC: compile-time class count (register arrays sized for it); NC == 0: any count up to HEAD_MAX_CLS.
+// Every thread keeps U pixels in flight per iteration (the loop is latency bound otherwise: one 16-byte load per
+// thread and ~200 VGPRs for 8 classes gave 89 us for 134 MB).
+template <typename T, int NC, int U>
+__global__ __launch_bounds__(256) void k_head_fwd(const T* __restrict__ y, const float* __restrict__ a,
+                                                  const float* __restrict__ b, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, int C, int ncls_rt, int HW, int LPP,
+                                                  float* __restrict__ logits_nhwc, float* __restrict__ logits_nchw) {
+  constexpr int V = VecIO<T>::V;
+  constexpr int KMAX = NC ? NC : HEAD_MAX_CLS;
+  const int ncls = NC ? NC : ncls_rt;
+  const int lane_in = threadIdx.x & (LPP - 1);
+  const int ppb = 256 / LPP;                 // pixels per block and unroll slot
+  const int grp = threadIdx.x / LPP;
+  const int bb = blockIdx.y;
+  float av[V], bv[V];
+  const bool bn = a != nullptr;
+  if (bn) load_coef<V>(a, b, lane_in * V, av, bv);
+  float wv[KMAX][V];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-      float d = 0.f;
-      if (k < ncls) {   // wave-uniform: unused classes cost no cross-lane traffic
-        d = z[0] * wv[k][0] + z[1] * wv[k][1] + z[2] * wv[k][2] + z[3] * wv[k][3];
-        for (int off = LPP >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-      }
-      acc[k] = d;
+  for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) wv[k][j] = (k < ncls) ? w[k * C + lane_in * V + j] : 0.f;
+  }
+  const T* yb = y + (size_t)bb * HW * C + lane_in * V;
+  for (int p0 = blockIdx.x * ppb * U; p0 < HW; p0 += gridDim.x * ppb * U) {
+    float z[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * ppb + grp;
+#pragma unroll
+      for (int j = 0; j < V; ++j) z[u][j] = 0.f;
+      if (p < HW) load_act<T, V>(yb + (size_t)p * C, av, bv, bn, z[u]);
     }
-    if (valid && lane_in == 0) {
 #pragma unroll
-      for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-        if (k < ncls) {
-          const float v = acc[k] + bias[k];
-          logits_nhwc[p * ncls + k] = v;
-          if (logits_nchw) {
-            const int64_t bb = p / HW;
-            const int pp = (int)(p % HW);
-            logits_nchw[(bb * ncls + k) * HW + pp] = v;
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * ppb + grp;
+      float acc[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        float d = 0.f;
+        if (k < ncls) {   // uniform
+          d = z[u][0] * wv[k][0] + z[u][1] * wv[k][1];   // same expression (and contraction) as the 4-wide original
+#pragma unroll
+          for (int j = 2; j < V; ++j) d = d + z[u][j] * wv[k][j];
+          d = group_sum_last(d, LPP);
+        }
+        acc[k] = d;
+      }
+      if (p < HW && lane_in == LPP - 1) {
+        const size_t pg = (size_t)bb * HW + p;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < ncls) {
+            const float v = acc[k] + bias[k];
+            logits_nhwc[pg * ncls + k] = v;
+            if (logits_nchw) logits_nchw[((size_t)bb * ncls + k) * HW + p] = v;
           }
         }
       }
@@ -835,20 +907,44 @@ __global__ void k_head_fwd(const T* __restrict__ y, const float* __restrict__ a,
   }
 }
 
+template <typename T>
+static bool head_geometry(int C, int* LPP) {
+  constexpr int V = 16 / (int)sizeof(T);
+  if (C % V != 0) return false;
+  *LPP = C / V;
+  return *LPP >= 1 && *LPP <= 16 && (*LPP & (*LPP - 1)) == 0;
+}
+
+template <typename T>
+static void launch_head_fwd_t(const T* y, const float* a, const float* b, const float* w, const float* bias, int C, int ncls,
+                              int B, int HW, int LPP, float* nhwc, float* nchw, hipStream_t s) {
+  constexpr int U = 4;
+  const int g = ceil_div(ceil_div(HW, (256 / LPP) * U), 2);
+#define FU_HEAD_FWD(NC)                                                                                              \
+  hipLaunchKernelGGL((k_head_fwd<T, NC, U>), dim3(g, B), dim3(256), 0, s, y, a, b, w, bias, C, ncls, HW, LPP, nhwc, nchw)
+  switch (ncls) {
+    case 1: FU_HEAD_FWD(1); break;
+    case 2: FU_HEAD_FWD(2); break;
+    case 3: FU_HEAD_FWD(3); break;
+    case 4: FU_HEAD_FWD(4); break;
+    default: FU_HEAD_FWD(0); break;
+  }
+#undef FU_HEAD_FWD
+}
+
 int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const float* w, const float* bias, int C,
                     int ncls, int B, int H, int W, float* logits_nhwc, float* logits_nchw, hipStream_t s) {
-  const int LPP = C / 4;
-  FU_REQUIRE(C % 4 == 0 && LPP >= 1 && LPP <= 16 && (LPP & (LPP - 1)) == 0,
-             "head: base channels must be 4, 8, 16, 32 or 64 (got %d)", C);
   FU_REQUIRE(ncls >= 1 && ncls <= HEAD_MAX_CLS, "head: n_classes must be 1..%d", HEAD_MAX_CLS);
-  const int64_t npix = (int64_t)B * H * W;
-  const int g = grid_for(npix * LPP, 256, 4096);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_head_fwd<float>, dim3(g), dim3(256), 0, s, (const float*)y, a, b, w, bias, C, ncls, npix,
-                       H * W, logits_nhwc, logits_nchw);
-  else
-    hipLaunchKernelGGL(k_head_fwd<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)y, a, b, w, bias, C, ncls, npix,
-                       H * W, logits_nhwc, logits_nchw);
+  FU_REQUIRE(B <= 65535, "head: batch too large (%d)", B);
+  const int HW = H * W;
+  int LPP;
+  if (p == PREC_F32) {
+    FU_REQUIRE(head_geometry<float>(C, &LPP), "head: base channels must be 4, 8, 16, 32 or 64 in fp32 (got %d)", C);
+    launch_head_fwd_t<float>((const float*)y, a, b, w, bias, C, ncls, B, HW, LPP, logits_nhwc, logits_nchw, s);
+  } else {
+    FU_REQUIRE(head_geometry<bf16_t>(C, &LPP), "head: base channels must be 8, 16, 32, 64 or 128 in bf16 (got %d)", C);
+    launch_head_fwd_t<bf16_t>((const bf16_t*)y, a, b, w, bias, C, ncls, B, HW, LPP, logits_nhwc, logits_nchw, s);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -1139,55 +1235,75 @@ int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int
 // ------------------------------------------------------------------------------------------------
 static constexpr int HB_BLOCKS = 2048;
 
-template <typename T>
-__global__ void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y, const float* __restrict__ a,
-                           const float* __restrict__ b, const float* __restrict__ w, int C, int ncls, int64_t npix,
-                           T* __restrict__ g, float* __restrict__ partials) {
+template <typename T, int NC, int U>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y,
+                                                  const float* __restrict__ a, const float* __restrict__ b,
+                                                  const float* __restrict__ w, int C, int ncls_rt, int npix, int LPP,
+                                                  T* __restrict__ g, float* __restrict__ partials) {
+  constexpr int V = VecIO<T>::V;
+  constexpr int KMAX = NC ? NC : HEAD_MAX_CLS;
+  const int ncls = NC ? NC : ncls_rt;
   extern __shared__ float sm[];  // [groups][ncls*C + ncls]
-  const int LPP = C >> 2;
-  const int lane_in = threadIdx.x % LPP;
+  const int lane_in = threadIdx.x & (LPP - 1);
   const int grp = threadIdx.x / LPP;
-  const int ppb = blockDim.x / LPP;
+  const int ppb = 256 / LPP;
   const int stride = ncls * C + ncls;
-  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+  float av[V], bv[V];
   const bool bn = a != nullptr;
-  if (bn) { ElemIO<float>::load4(a + lane_in * 4, av); ElemIO<float>::load4(b + lane_in * 4, bv); }
-  float wv[HEAD_MAX_CLS][4], dw[HEAD_MAX_CLS][4], db[HEAD_MAX_CLS];
+  if (bn) load_coef<V>(a, b, lane_in * V, av, bv);
+  float wv[KMAX][V], dw[KMAX][V], db[KMAX];
 #pragma unroll
-  for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-    if (k < ncls) ElemIO<float>::load4(w + k * C + lane_in * 4, wv[k]);
-    else wv[k][0] = wv[k][1] = wv[k][2] = wv[k][3] = 0.f;
-    dw[k][0] = dw[k][1] = dw[k][2] = dw[k][3] = 0.f;
+  for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { wv[k][j] = (k < ncls) ? w[k * C + lane_in * V + j] : 0.f; dw[k][j] = 0.f; }
     db[k] = 0.f;
   }
-  const int64_t niter = ceil_div64(npix, ppb);
-  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
-    const int64_t p = it * ppb + grp;
-    if (p < npix) {
-      float z[4], o[4] = {0, 0, 0, 0};
-      load_act4<T>(y + p * C + lane_in * 4, av, bv, bn, z);
+  // U pixels per thread in flight per iteration; dW / db are summed per thread in visiting order, then per block in
+  // LDS and over the blocks in k_head_bwd_finalize (fixed order, deterministic)
+  for (int p0 = blockIdx.x * ppb * U; p0 < npix; p0 += gridDim.x * ppb * U) {
+    float z[U][V], d[U][KMAX];
 #pragma unroll
-      for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-        if (k < ncls) {
-          const float d = dl[p * ncls + k];
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * ppb + grp;
+      const bool ok = p < npix;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { o[j] += d * wv[k][j]; dw[k][j] += d * z[j]; }
-          db[k] += d;
+      for (int j = 0; j < V; ++j) z[u][j] = 0.f;
+      if (ok) load_act<T, V>(y + (size_t)p * C + lane_in * V, av, bv, bn, z[u]);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) d[u][k] = (ok && k < ncls) ? dl[(size_t)p * ncls + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * ppb + grp;
+      if (p < npix) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < ncls) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { o[j] += d[u][k] * wv[k][j]; dw[k][j] += d[u][k] * z[u][j]; }
+            db[k] += d[u][k];
+          }
         }
+        VecIO<T>::store(g + (size_t)p * C + lane_in * V, o);
       }
-      ElemIO<T>::store4(g + p * C + lane_in * 4, o);
     }
   }
-  for (int k = 0; k < ncls; ++k) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm[grp * stride + k * C + lane_in * 4 + j] = dw[k][j];
-    if (lane_in == 0) sm[grp * stride + ncls * C + k] = db[k];
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < ncls) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) sm[grp * stride + k * C + lane_in * V + j] = dw[k][j];
+      if (lane_in == 0) sm[grp * stride + ncls * C + k] = db[k];
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < stride; e += blockDim.x) {
     float t = 0.f;
     for (int gq = 0; gq < ppb; ++gq) t += sm[gq * stride + e];
-    partials[(int64_t)blockIdx.x * stride + e] = t;
+    partials[(size_t)blockIdx.x * stride + e] = t;
   }
 }
 
@@ -1212,19 +1328,38 @@ int64_t head_bwd_partial_elems(int C, int ncls) { return (int64_t)HB_BLOCKS * (n
 
 int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
                     int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s) {
-  const int LPP = C / 4;
+  FU_REQUIRE(npix < ((int64_t)1 << 31), "head_bwd: too many pixels");
+  int LPP;
+  if (p == PREC_F32) FU_REQUIRE(head_geometry<float>(C, &LPP), "head_bwd: unsupported channel count %d", C);
+  else FU_REQUIRE(head_geometry<bf16_t>(C, &LPP), "head_bwd: unsupported channel count %d", C);
+  constexpr int U = 4;
   const int ppb = 256 / LPP;
-  int nblk = (int)ceil_div64(npix, ppb);
+  int nblk = (int)ceil_div64(npix, (int64_t)ppb * U);
   if (nblk > HB_BLOCKS) nblk = HB_BLOCKS;
   const int stride = ncls * C + ncls;
   const size_t sh = (size_t)ppb * stride * sizeof(float);
   FU_REQUIRE(sh <= 64 * 1024, "head_bwd: LDS request too large (%zu)", sh);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_head_bwd<float>, dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const float*)y, a, b, w, C, ncls,
-                       npix, (float*)g, partials);
-  else
-    hipLaunchKernelGGL(k_head_bwd<bf16_t>, dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const bf16_t*)y, a, b, w, C,
-                       ncls, npix, (bf16_t*)g, partials);
+#define FU_HEAD_BWD(TT, NC)                                                                                     \
+  hipLaunchKernelGGL((k_head_bwd<TT, NC, U>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, w, C, ncls, \
+                     (int)npix, LPP, (TT*)g, partials)
+  if (p == PREC_F32) {
+    switch (ncls) {
+      case 1: FU_HEAD_BWD(float, 1); break;
+      case 2: FU_HEAD_BWD(float, 2); break;
+      case 3: FU_HEAD_BWD(float, 3); break;
+      case 4: FU_HEAD_BWD(float, 4); break;
+      default: FU_HEAD_BWD(float, 0); break;
+    }
+  } else {
+    switch (ncls) {
+      case 1: FU_HEAD_BWD(bf16_t, 1); break;
+      case 2: FU_HEAD_BWD(bf16_t, 2); break;
+      case 3: FU_HEAD_BWD(bf16_t, 3); break;
+      case 4: FU_HEAD_BWD(bf16_t, 4); break;
+      default: FU_HEAD_BWD(bf16_t, 0); break;
+    }
+  }
+#undef FU_HEAD_BWD
   FU_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 8)), dim3(256), 0, s, partials, nblk, C, ncls, dw, db);
   FU_LAUNCH_CHECK();
