@@ -930,7 +930,7 @@ int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* tota
   if (total_flops) *total_flops = fl;
   if (kernel_name)
     *kernel_name = kernel_class == FU_K_CONV3X3
-                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : "k_conv3x3_bf16")
+                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : "k_conv3x3_bf16_fast")
                        : (c->prec == PREC_F32 ? "k_wgrad_f32" : "k_wgrad_bf16");
   return FU_OK;
 }

@@ -10,7 +10,7 @@ from floodplanet_code_amd._lib import check, ptr
 lib = _lib.load()
 DEV = 'cuda:0'
 
-def run(B, C0, C1, Cout, H, W, general=0):
+def run(B, C0, C1, Cout, H, W, general=0, path=0):
     g = torch.Generator(device='cpu').manual_seed(0)
     x0 = torch.randn(B, H, W, C0, generator=g).to(DEV).to(torch.bfloat16)
     x1 = torch.randn(B, H, W, C1, generator=g).to(DEV).to(torch.bfloat16) if C1 else None
