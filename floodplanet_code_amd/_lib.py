@@ -41,6 +41,7 @@ class FloodUNetError(RuntimeError):
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
+SYNC_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)   # fu_sync_hook
 _f = C.c_float
 
 # name -> (restype, argtypes).  Every symbol include/floodunet.h declares is listed here; the
@@ -75,6 +76,8 @@ SIGNATURES = {
     "fu_flops_per_tile": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fu_profile_enable": (_i, [_p, _i]),
     "fu_test_force_general_conv": (None, [_i]),
+    "fu_set_exact_sync": (_i, [_p, SYNC_HOOK, _p, _i, _p, _i64]),
+    "fu_exact_sync_bytes": (_i64, [_p]),
     "fu_profile_read": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                              C.POINTER(C.c_char_p)]),
     "fu_elem_size": (_i, [_i]),

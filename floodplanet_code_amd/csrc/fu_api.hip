@@ -265,6 +265,7 @@ struct fu_ctx {
   float* bnb_part = nullptr;
   float* db_part = nullptr;
   double* dscratch = nullptr;
+  fu::SyncDesc sync;           // exact data-parallel mode (fu_set_exact_sync); hook == nullptr: off
   float* slab = nullptr;
   float* ce_part = nullptr;
   float* hb_part = nullptr;
@@ -798,8 +799,31 @@ int fu_params_changed(fu_ctx* c) {
   return FU_OK;
 }
 
+namespace {
+struct SyncScope {   // makes the context's exact-sync descriptor visible to the launchers for one API call
+  explicit SyncScope(const fu_ctx* c, bool on) { fu::g_sync = (on && c && c->sync.hook) ? &c->sync : nullptr; }
+  ~SyncScope() { fu::g_sync = nullptr; }
+};
+}  // namespace
+
+int fu_set_exact_sync(fu_ctx* c, fu_sync_hook hook, void* user, int world, void* exchange, int64_t exchange_bytes) {
+  FU_REQUIRE(c, "null context");
+  if (!hook || world <= 1) { c->sync = fu::SyncDesc(); return FU_OK; }
+  FU_REQUIRE(exchange && exchange_bytes >= fu_exact_sync_bytes(c), "fu_set_exact_sync: exchange buffer of at least %lld bytes needed",
+             (long long)fu_exact_sync_bytes(c));
+  c->sync.hook = hook; c->sync.user = user; c->sync.world = world; c->sync.xbuf = exchange; c->sync.xbytes = exchange_bytes;
+  return FU_OK;
+}
+int64_t fu_exact_sync_bytes(const fu_ctx* c) {
+  if (!c) return 0;
+  int max_c = 64;
+  for (const BnInfo& b : c->bns) max_c = std::max(max_c, b.C);
+  return std::max<int64_t>(fu::reduce_scratch_elems(max_c) * (int64_t)sizeof(double), 2 * 1024 * (int64_t)sizeof(float));
+}
+
 int fu_forward(fu_ctx* c, const float* x, int batch, int training, float* logits_out, fu_stream stream) {
   FU_TRY(check_fwd_args(c, x, batch));
+  SyncScope sc(c, training != 0);   // eval-mode BN uses the running statistics: nothing to exchange
   return forward_impl(c, x, batch, training != 0, logits_out, (hipStream_t)stream);
 }
 
@@ -808,6 +832,7 @@ int fu_loss_ce(fu_ctx* c, const int64_t* target, int ignore_index, float* loss_o
   FU_REQUIRE(c && target, "fu_loss_ce: null argument");
   FU_REQUIRE(c->last_batch > 0, "fu_loss_ce: no forward pass yet");
   hipStream_t s = (hipStream_t)stream;
+  SyncScope sc(c, c->fwd_training);
   const int64_t npix = (int64_t)c->last_batch * c->cfg.height * c->cfg.width;
   FU_TRY(launch_ce_loss(c->logits, target, c->cfg.n_classes, ignore_index, npix, c->ce_part,
                         loss_out ? loss_out : c->loss_dev, c->n_valid, confusion_out, n_valid_out, c->conf_tmp, s));
@@ -841,6 +866,7 @@ int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stre
     return FU_ERR_STATE;
   }
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
+  SyncScope sc(c, true);
   return backward_block_impl(c, block, dlogits, (hipStream_t)stream);
 }
 

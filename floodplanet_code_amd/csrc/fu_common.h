@@ -149,6 +149,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct ProfSlot { hipEvent_t start = nullptr; hipEvent_t stop = nullptr; };
 extern thread_local ProfSlot g_prof_slot;
 
+// Exact data-parallel mode (fu_set_exact_sync): at every statistics reduction the partial sums are summed over the
+// ranks before they are finalised.  The API layer points g_sync at the context's descriptor for the duration of a
+// call; the three launchers with such a reduction (BN forward statistics, BN backward sums, CE loss sums) check it.
+struct SyncDesc {
+  int (*hook)(void* user, int64_t n_elems, int is_double) = nullptr;   // sums xbuf[0..n) over the ranks, in place
+  void* user = nullptr;
+  void* xbuf = nullptr;        // caller-owned device exchange buffer
+  int64_t xbytes = 0;
+  int world = 1;
+};
+extern thread_local const SyncDesc* g_sync;
+// payload (device, n elements of float or double) -> xbuf, hook, back; no-op without an active descriptor
+int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s);
+static inline int sync_world() { return (g_sync && g_sync->hook) ? g_sync->world : 1; }
+
 // ---- kernel launchers (implemented in the .hip files) ----------------------------------------
 // All pointers are device pointers; T-typed buffers are `void*` + Prec.
 

@@ -8,6 +8,23 @@
 
 namespace fu {
 
+thread_local const SyncDesc* g_sync = nullptr;
+
+int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s) {
+  const SyncDesc* d = g_sync;
+  if (!d || !d->hook || d->world <= 1) return 0;
+  const size_t bytes = (size_t)n_elems * (is_double ? 8 : 4);
+  FU_REQUIRE((int64_t)bytes <= d->xbytes, "exact sync: exchange buffer too small (%zu > %lld bytes)", bytes,
+             (long long)d->xbytes);
+  FU_HIP_CHECK(hipMemcpyAsync(d->xbuf, payload, bytes, hipMemcpyDeviceToDevice, s));
+  if (d->hook(d->user, n_elems, is_double ? 1 : 0) != 0) {
+    set_error("exact sync: the all-reduce hook failed");
+    return 3;   // FU_ERR_STATE
+  }
+  FU_HIP_CHECK(hipMemcpyAsync(payload, d->xbuf, bytes, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // error message storage
 // ------------------------------------------------------------------------------------------------
@@ -194,7 +211,9 @@ int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, 
                        hipStream_t s) {
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nTiles, C, s, &G));
-  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C, (double)count,
+  FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global batch statistics
+  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
+                     (double)count * sync_world(),
                      conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt);
   FU_LAUNCH_CHECK();
   return 0;
@@ -275,7 +294,8 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ dpart, int G, int C,
-                                                         double count, float* __restrict__ dgamma,
+                                                         double count, double grad_share,
+                                                         float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
   const int g = threadIdx.x & 31;
   const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -285,8 +305,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restric
   S1 = half_wave_sum(S1);
   S2 = half_wave_sum(S2);
   if (c >= C || g != 0) return;
-  if (dbeta) dbeta[c] = (float)S1;
-  if (dgamma) dgamma[c] = (float)S2;
+  // (exact DP: S1, S2 are sums over all ranks; the parameter gradients are summed over the ranks afterwards, so each
+  //  rank contributes 1/world of them)
+  if (dbeta) dbeta[c] = (float)(S1 * grad_share);
+  if (dgamma) dgamma[c] = (float)(S2 * grad_share);
   coef[c * 2 + 0] = (float)(S1 / count);
   coef[c * 2 + 1] = (float)(S2 / count);
 }
@@ -365,8 +387,9 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   FU_LAUNCH_CHECK();
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C, (double)npix,
-                     dgamma, dbeta, coef);
+  FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global sums of g and g*xhat
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
+                     (double)npix * sync_world(), 1.0 / sync_world(), dgamma, dbeta, coef);
   FU_LAUNCH_CHECK();
   const size_t sh2 = (size_t)rows * C * sizeof(float);
   if (p == PREC_F32)
@@ -1040,6 +1063,7 @@ int launch_ce_loss(const float* logits_nhwc, const int64_t* target, int ncls, in
   hipLaunchKernelGGL(k_ce_loss, dim3(nblk), dim3(CE_BLOCK), 0, s, logits_nhwc, target, ncls, ignore_index, npix,
                      partials, conf_tmp);
   FU_LAUNCH_CHECK();
+  FU_TRY(sync_sum_over_ranks(partials, (int64_t)nblk * 2, false, s));      // exact DP: global loss sum and N_valid
   hipLaunchKernelGGL(k_ce_finalize, dim3(1), dim3(256), 0, s, partials, nblk, ncls, loss_out, n_valid_dev, conf_tmp,
                      confusion_accum, n_valid_out);
   FU_LAUNCH_CHECK();

@@ -1,8 +1,10 @@
 """One-process-per-GPU data parallelism for the UNet training step (new functionality: the reference trains
 on a single device, st_water_seg/fit.py:87-88, so the semantics are defined here and in DESIGN.md):
 
-  * DDP semantics: per-rank BatchNorm statistics and per-rank 1/N_valid loss normaliser, gradients averaged
+  * default = DDP semantics: per-rank BatchNorm statistics and per-rank 1/N_valid loss normaliser, gradients averaged
     over ranks (sum all-reduce, 1/world folded into the Adam kernel's grad_scale).
+  * exact=True: SyncBN statistics (forward and backward sums) and a global N_valid through fu_set_exact_sync, gradients
+    summed: W ranks x B tiles reproduce one device with W*B tiles up to fp32 summation order (the parity mode).
   * the only exchange is the gradient all-reduce over RCCL (torch.distributed backend "nccl").  Backward runs
     block by block (fu_backward_block); as soon as the blocks of a bucket are final, the bucket -- one contiguous
     slice of the flat gradient buffer -- is all-reduced asynchronously on RCCL's stream while the remaining
@@ -71,9 +73,15 @@ class DataParallelTrainer:
     """fwd + CE + block-wise bwd (+ overlapped all-reduce) + fused Adam on a HipUNet."""
 
     def __init__(self, net, lr: float, world_size: int = 1, rank: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None, cap_bytes: int = 25 << 20):
+                 group=None, cap_bytes: int = 25 << 20, exact: bool = False):
+        """exact=False: DDP semantics (per-rank BN statistics and 1/N_valid, gradients averaged).
+        exact=True: SyncBN statistics and a global N_valid (HipUNet.enable_exact_sync); the ranks together reproduce
+        one device with world_size x the batch, gradients are summed (SURVEY.md 8(e) "exact mode")."""
         self.net, self.lr, self.world_size, self.rank = net, lr, world_size, rank
         self.betas, self.eps, self.group, self.cap_bytes = betas, eps, group, cap_bytes
+        self.exact = bool(exact) and world_size > 1
+        if self.exact:
+            net.enable_exact_sync(world_size, group)
         self.step_count = 0
         self._reducer: Optional[BucketedReducer] = None
         self._synced = False
@@ -107,5 +115,6 @@ class DataParallelTrainer:
                 self._reducer.block_done(flat, b)
             self._reducer.finish()
         self.step_count += 1
-        net.adam_step(self.lr, self.step_count, self.betas, self.eps, grad_scale=1.0 / self.world_size)
+        net.adam_step(self.lr, self.step_count, self.betas, self.eps,
+                      grad_scale=1.0 if self.exact else 1.0 / self.world_size)
         return loss

@@ -130,6 +130,7 @@ class HipUNet(nn.Module):
         self._ctx_key = None
         self._eval_dirty = True
         self._confusion: Optional[torch.Tensor] = None
+        self._exact = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # ---------------------------------------------------------------- flat storage
@@ -211,7 +212,43 @@ class HipUNet(nn.Module):
         check(lib.fu_bind_buffers(h, ptr(self._flat), ptr(self._flat_grad), ptr(self._flat_rm), ptr(self._flat_rv),
                                   ptr(self._flat_nbt)))
         self._eval_dirty = True
+        self._install_exact_sync(device)
         return h
+
+    # ---------------------------------------------------------------- exact data-parallel mode
+    def enable_exact_sync(self, world_size: int, group=None, enabled: bool = True):
+        """SyncBN statistics + global N_valid over the ranks of `group` (include/floodunet.h, fu_set_exact_sync):
+        W ranks x B tiles then reproduce one device with W*B tiles.  Gradients hold each rank's share of the global
+        gradient afterwards: all-reduce them with SUM and use grad_scale 1 (DataParallelTrainer(exact=True))."""
+        self._exact = (int(world_size), group) if enabled and world_size > 1 else None
+        if self._ctx is not None:
+            self._install_exact_sync(self._flat.device)
+
+    def _install_exact_sync(self, device):
+        lib = _lib.load()
+        exact = getattr(self, "_exact", None)
+        if exact is None:
+            if self._ctx is not None:
+                check(lib.fu_set_exact_sync(self._ctx, _lib.SYNC_HOOK(0), None, 1, None, 0))   # null hook: off
+            return
+        import torch.distributed as dist
+        world, group = exact
+        nbytes = int(lib.fu_exact_sync_bytes(self._ctx))
+        self._xbuf = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=device)
+        xbuf = self._xbuf
+
+        def hook(_user, n_elems, is_double):
+            try:
+                t = xbuf[:n_elems] if is_double else xbuf.view(torch.float32)[:n_elems]
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # ordered on the current stream
+                return 0
+            except Exception:   # never let an exception cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._sync_cb = _lib.SYNC_HOOK(hook)     # keep the callback object alive as long as the context
+        check(lib.fu_set_exact_sync(self._ctx, self._sync_cb, None, world, ptr(xbuf), nbytes))
 
     def _verify_table(self):
         lib = _lib.load()

@@ -139,6 +139,20 @@ int fu_adam_step(fu_ctx* ctx, float lr, float beta1, float beta2, float eps, int
 int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* device pointers, for checkpoints */
 int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
 
+/* ---- exact data-parallel mode (SyncBN statistics + global N_valid) ----------------
+ * The reference trains on one device; with tiles sharded over ranks the default (DDP) semantics use per-rank
+ * BatchNorm statistics and a per-rank 1/N_valid.  After fu_set_exact_sync every training fu_forward / fu_loss_ce /
+ * fu_backward* sums its statistics partials over the ranks before they are finalised -- BN forward (sum y, sum y^2),
+ * BN backward (sum g, sum g*xhat), CE (sum loss, N_valid) -- so that W ranks x B tiles reproduce one device with W*B
+ * tiles up to fp32 summation order.  At each of those points the library copies the partials into `exchange`
+ * (caller-owned device memory, >= fu_exact_sync_bytes), calls hook(user, n_elems, is_double) -- which must sum
+ * exchange[0..n_elems) (double or float) over the ranks in place, ordered on the stream of the running call -- and
+ * copies the result back.  Parameter gradients then hold each rank's SHARE of the global gradient: all-reduce them with
+ * SUM and call fu_adam_step with grad_scale 1.  world <= 1 or hook == NULL switches the mode off. */
+typedef int (*fu_sync_hook)(void* user, int64_t n_elems, int is_double);
+int fu_set_exact_sync(fu_ctx* ctx, fu_sync_hook hook, void* user, int world, void* exchange, int64_t exchange_bytes);
+int64_t fu_exact_sync_bytes(const fu_ctx* ctx);
+
 /* ---- on-GPU tile augmentation (datasets/base_dataset.py:494-555) ------- */
 /* Per sample b: hflip (flags[b] & 1), then vflip (& 2), then rotate by angles_deg[b] (& 4) with torchvision's
  * tensor semantics (nearest, expand=False, centre = image centre, image fill 0), applied identically to
