@@ -67,8 +67,7 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
 // (experimental/fu_conv_bf16_pp.hip: persistent two-group ping-pong variant, not built: 8 % slower)
 int launch_conv3x3_bf16_pp(BConvP& P, hipStream_t s);
-// (experimental/fu_conv_bf16_pipe.hip holds a persistent, software-pipelined variant with this launcher; it is not
-// built: measured 8-14 % slower than the fast kernel)
-int launch_conv3x3_bf16_pipe(BConvP& P, hipStream_t s);
+// (csrc/experimental/ holds two measured-slower restructurings of the fast kernel, fu_conv_bf16_pipe.hip and
+//  fu_conv_bf16_pp.hip, with launchers launch_conv3x3_bf16_pipe / _pp of this same signature; they are not built)
 
 }  // namespace fu

@@ -16,8 +16,9 @@
 #include "fu_conv_bf16.h"
 
 #ifndef FU_FAST_DBG
-#define FU_FAST_DBG 0   // experiments: 4 = epilogue without global stores
-#endif
+#define FU_FAST_DBG 0   // diagnostic builds (make EXTRA=-DFU_FAST_DBG=4): 4 = epilogue without its global stores
+#endif                  // (64->64 @256^2: 114.8 -> 92.2 us).  -DFU_CONV_STAMPS: s_memtime stamps for
+                        // tools/stamp_test.py.  Neither is ever defined in the shipped build.
 
 namespace fu {
 
