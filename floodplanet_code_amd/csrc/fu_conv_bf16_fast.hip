@@ -188,30 +188,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     for (int c = tid; c < P.C0; c += NT) { sAB[c] = P.a0[c]; sAB[1024 + c] = P.b0[c]; }
   }
 #ifdef FU_CONV_STAMPS
-  unsigned long long Sbar = 0, Swait = 0, Sstore = 0, Smfma = 0, tp = T0;
+  unsigned long long Sbar = 0, Swait = 0, Sstore = 0, Smfma = 0;   // (per-phase sums: only in older diagnostic builds)
 #endif
-  for (int ch = 0; ch < nChunks; ++ch) {
-    const int k0 = ch * KC;
-    __syncthreads();            // previous chunk's fragment reads are done (and sAB is visible on the first pass)
-#ifdef FU_CONV_STAMPS
-    const unsigned long long ta = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long tw = __builtin_amdgcn_s_memtime();
-#endif
-    if (border || k0 + KC > P.Cin) store_chunk(k0, std::true_type{});
-    else store_chunk(k0, std::false_type{});
-    __syncthreads();
-#ifdef FU_CONV_STAMPS
-    const unsigned long long tb = __builtin_amdgcn_s_memtime();
-    Sbar += ta - tp; Swait += tw - ta; Sstore += tb - tw;
-    if (ch == 0) T1 = tb;
-#endif
-    if (ch + 1 < nChunks) {
-      if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // next chunk starts the second source
-      load_chunk(k0 + KC);                                      // raw loads stay in flight under the MFMA block
-    }
-    // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
-    // s+1 are requested from LDS before the MFMAs of step s are issued.
+  // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
+  // s+1 are requested from LDS before the MFMAs of step s are issued.
+  auto mfma_block = [&]() {
     bf16x8 af[2][2], bfr[2][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
@@ -236,11 +217,32 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
         for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
     });
+  };
+  auto stage = [&](int k0) {
+    __syncthreads();            // previous chunk's fragment reads are done (and sAB is visible on the first pass)
+    if (border || k0 + KC > P.Cin) store_chunk(k0, std::true_type{});
+    else store_chunk(k0, std::false_type{});
+    __syncthreads();
+  };
+  // The last chunk is peeled so that the loop body ALWAYS issues the next chunk's loads.  With the loads under
+  // `if (ch + 1 < nChunks)` the staging registers became phis of a loaded and a not-loaded path, hipcc copied two of
+  // them right behind the loads and put `s_waitcnt vmcnt(9)` in front of the MFMA block: every chunk then waited for
+  // the next chunk's first six loads (a full memory latency) before its first MFMA.
+  for (int ch = 0; ch + 1 < nChunks; ++ch) {
+    const int k0 = ch * KC;
+    stage(k0);
 #ifdef FU_CONV_STAMPS
-    tp = __builtin_amdgcn_s_memtime();
-    Smfma += tp - tb;
+    if (ch == 0) T1 = __builtin_amdgcn_s_memtime();
 #endif
+    if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // next chunk starts the second source
+    load_chunk(k0 + KC);                                      // raw loads stay in flight under the MFMA block
+    mfma_block();
   }
+  stage((nChunks - 1) * KC);
+#ifdef FU_CONV_STAMPS
+  if (nChunks == 1) T1 = __builtin_amdgcn_s_memtime();
+#endif
+  mfma_block();
 #ifdef FU_CONV_STAMPS
   T2 = __builtin_amdgcn_s_memtime();
 #endif

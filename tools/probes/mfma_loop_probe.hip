@@ -51,6 +51,88 @@ __global__ __launch_bounds__(512) void k_loop(unsigned long long* out, float* si
   if (lane == 0) out[blockIdx.x * (blockDim.x / 64) + (tid >> 6)] = t1 - t0;
 }
 
+// Two waves per SIMD: waves 0..3 run the MFMA + fragment-read loop, waves 4..7 imitate the other workgroup's staging
+// phase (WR ds_write_b128 + VA dependent-free VALU instructions per k-block) until the MFMA waves are done.
+template <int WR, int VA, int GL = 0>
+__global__ __launch_bounds__(512) void k_loop_vs_stager(unsigned long long* out, float* sink, int iters, int* flag, const uint4* gsrc = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* sS = reinterpret_cast<unsigned short*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv & 3, l31 = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < 2 * STAGE; i += blockDim.x) sS[i] = 0x3c00 + (i & 63);
+  __shared__ int done;
+  if (tid == 0) done = 0;
+  __syncthreads();
+  if (wv >= 4) {   // stager: writes go to the SECOND stage (no data race with the readers)
+    uint4 v = make_uint4(tid, tid + 1, tid + 2, tid + 3);
+    float a = tid * 0.5f, b = 1.25f;
+    unsigned short* dst = sS + STAGE + ((tid & 255) >> 2) * KCP + 8 * (tid & 3);
+    unsigned long long n = 0;
+    while (*(volatile int*)&done < 4) {
+#pragma unroll
+      for (int w = 0; w < WR; ++w) {
+        *reinterpret_cast<uint4*>(dst + w * 64 * KCP) = v;
+#pragma unroll
+        for (int q = 0; q < VA / (WR > 0 ? WR : 1); ++q) { a = a * b + 0.5f; v.x += (unsigned)a; }
+      }
+      if (WR == 0) {
+#pragma unroll
+        for (int q = 0; q < VA; ++q) { a = a * b + 0.5f; v.x += (unsigned)a; }
+      }
+      ++n;
+    }
+    if (a == 12345.f) sink[1] = a + v.x;
+    if (lane == 0) out[blockIdx.x * 8 + wv] = n;
+    return;
+  }
+  int aoff[2], boff[2];
+  const int mrow = l31 >> 4, mcol = mrow ? ((l31 - 16 - 2) & 15) : l31;
+  for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wm * 2 + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
+  for (int nt = 0; nt < 2; ++nt) boff[nt] = NHP * KCP + (nt * 32 + l31) * KCP + 8 * lh;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 af[3][2], bfr[3][2];
+  auto load_frag = [&](auto Sc, auto Rc) {
+    constexpr int st = decltype(Sc)::value, r = decltype(Rc)::value, buf = st % 3, tap = st >> 1, ks = st & 1;
+    if constexpr (r < 2) af[buf][r] = *reinterpret_cast<const bf16x8*>(sS + aoff[r] + ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16);
+    else bfr[buf][r - 2] = *reinterpret_cast<const bf16x8*>(sS + boff[r - 2] + tap * BN * KCP + ks * 16);
+  };
+  uint4 rg[GL > 0 ? GL : 1];
+  unsigned gsum = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (GL > 0) {   // the next chunk's raw global loads, in flight under the MFMA block (L2-resident source)
+      static_for<0, GL>([&](auto I) { rg[decltype(I)::value] = gsrc[((blockIdx.x * 8 + it) & 1023) * 4096 + decltype(I)::value * 256 + (tid & 255)]; });
+    }
+    static_for<0, 1>([&](auto Sc) { static_for<0, 4>([&](auto Rc) { load_frag(Sc, Rc); }); });
+    static_for<0, 72>([&](auto Mc) {
+      constexpr int m = decltype(Mc)::value, st = m / 4, j = m % 4, mt = j / 2, nt = j % 2;
+      if constexpr (st + 1 < 18) load_frag(std::integral_constant<int, st + 1>{}, std::integral_constant<int, j>{});
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st % 3][mt], bfr[st % 3][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (GL > 0) static_for<0, GL>([&](auto I) { gsum += rg[decltype(I)::value].x; });
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (gsum == 0x12345u) sink[2] = 1.f;
+  if (lane == 0) atomicAdd(&done, 1);
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[0] = s;
+  if (lane == 0) out[blockIdx.x * 8 + wv] = t1 - t0;
+}
+
+template <int WR, int VA, int GL = 0>
+void run_vs(const char* name, unsigned long long* out, float* sink, const uint4* gsrc = nullptr) {
+  const int iters = 50;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop_vs_stager<WR, VA, GL>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE * 2);
+  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k_loop_vs_stager<WR, VA, GL>), dim3(256), dim3(512), 2 * STAGE * 2, 0, out, sink, iters, nullptr, gsrc);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(256 * 8);
+  hipMemcpy(h.data(), out, 256 * 8 * 8, hipMemcpyDeviceToHost);
+  double s = 0, n = 0; for (int b = 0; b < 256; ++b) { for (int w = 0; w < 4; ++w) s += h[b * 8 + w]; for (int w = 4; w < 8; ++w) n += h[b * 8 + w]; }
+  printf("%-58s MFMA waves: %.1f ticks per k-step; stager iterations per MFMA block: %.2f\n", name, s / 1024 / iters / 18.0, n / 1024 / iters);
+}
+
 template <int MODE, int DIST>
 void run(const char* name, int threads, unsigned long long* out, float* sink) {
   const int iters = 50, nw = 256 * threads / 64;
@@ -70,5 +152,13 @@ int main() {
     run<1, 1>("MFMA + ds_read_b128 frags, distance 1", threads, out, sink);
     run<1, 2>("MFMA + ds_read_b128 frags, distance 2", threads, out, sink);
   }
+  printf("--- MFMA loop (waves 0-3) against a staging partner wave on every SIMD (waves 4-7)\n");
+  run_vs<0, 0>("partner spinning on the flag only", out, sink);
+  run_vs<0, 128>("partner: 128 VALU per iteration", out, sink);
+  run_vs<15, 0>("partner: 15 ds_write_b128 per iteration", out, sink);
+  run_vs<15, 120>("partner: 15 ds_write_b128 + 120 VALU per iteration", out, sink);
+  uint4* gsrc; hipMalloc(&gsrc, (size_t)1024 * 4096 * 16); hipMemset(gsrc, 1, (size_t)1024 * 4096 * 16);
+  run_vs<0, 128, 15>("15 global_load_dwordx4 per block in flight; partner VALU", out, sink, gsrc);
+  run_vs<15, 120, 15>("15 global loads in flight; partner 15 ds_write + 120 VALU", out, sink, gsrc);
   return 0;
 }
