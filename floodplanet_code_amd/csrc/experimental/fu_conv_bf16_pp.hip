@@ -117,40 +117,49 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
 
   uint4 ra[A_ITERS];
   uint4 rw[W_ITERS];
-  auto load_chunk = [&]() {     // chunk chL of tile tl -> staging registers
+  // chunk chL of tile tl -> staging registers, one 16-byte load per slot (slots 0..A_ITERS-1: halo tile, then weights)
+  const char* abL = nullptr;
+  const char* wbL = nullptr;
+  unsigned cmL = 0, woL = 0;
+  auto load_begin = [&]() {
     const int k0 = chL * KC;
     const bool s1 = P.src1 != nullptr && k0 >= P.C0;            // uniform: C0 % 32 == 0 with two sources
-    const char* ab = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
-                        : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
-    const char* wb = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
-    const unsigned cm = (k0 + 8 * aq < P.Cin) ? 0xffffffffu : 0u;   // ragged last chunk: octets past Cin
-    static_for<0, A_ITERS>([&](auto I) {
-      constexpr int it = decltype(I)::value;
-      ra[it] = *reinterpret_cast<const uint4*>(ab + (a_off[it] & cm));
-    });
-    const unsigned wo = w_off & cm;
-    static_for<0, W_ITERS>([&](auto I) {
-      constexpr int it = decltype(I)::value;
-      if (it < Cfg::W_FULL || wm < Cfg::W_REM / 64)
-        rw[it] = *reinterpret_cast<const uint4*>(wb + (wo + (unsigned)it * w_step));
-    });
+    abL = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
+             : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
+    wbL = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
+    cmL = (k0 + 8 * aq < P.Cin) ? 0xffffffffu : 0u;             // ragged last chunk: octets past Cin
+    woL = w_off & cmL;
   };
-  // the staging registers hold chunk (jS, chS) = the load cursor before its last advance
-  int chS = 0;
-  bool borderS = false;
-  unsigned a_okS = 0;
-  auto advance_load = [&]() {   // remember what the registers hold, move the cursor, issue the next loads
-    chS = chL; borderS = borderL; a_okS = a_ok;
+  auto load_slot = [&](auto Sc) {
+    constexpr int sl = decltype(Sc)::value;
+    if constexpr (sl < A_ITERS) {
+      ra[sl] = *reinterpret_cast<const uint4*>(abL + (a_off[sl] & cmL));
+    } else if constexpr (sl < A_ITERS + W_ITERS) {
+      constexpr int it = sl - A_ITERS;
+      if (it < Cfg::W_FULL || wm < Cfg::W_REM / 64)
+        rw[it] = *reinterpret_cast<const uint4*>(wbL + (woL + (unsigned)it * w_step));
+    }
+  };
+  auto load_chunk = [&]() {
+    load_begin();
+    static_for<0, A_ITERS + W_ITERS>([&](auto Sc) { load_slot(Sc); });
+  };
+  // R: the chunk in (or on its way into) the staging registers; M: the chunk in this group's LDS stage
+  int jR = 0, chR = 0, jM = 0, chM = 0;
+  bool borderR = false;
+  unsigned a_okR = 0;
+  auto advance_load = [&]() {   // registers now hold the cursor's chunk: remember it, move the cursor on
+    jR = jL; chR = chL; borderR = borderL; a_okR = a_ok;
     if (++chL == nChunks) { chL = 0; ++jL; setup_tile(); }
     else if (P.src1 != nullptr && chL * KC == P.C0) setup_a(P.C1);
   };
 
-  auto store_chunk = [&](auto Mc) {   // staging registers (chunk chS) -> this group's LDS stage
+  auto store_chunk = [&](auto Mc) {   // staging registers (chunk R) -> this group's LDS stage
     constexpr bool MASKED = decltype(Mc)::value;
-    const int k0 = chS * KC;
+    const int k0 = chR * KC;
     const bool bn = has_bn && k0 < P.C0;                        // uniform
     unsigned km = 0;
-    if constexpr (MASKED) km = (k0 + 8 * aq < P.Cin) ? a_okS : 0u;
+    if constexpr (MASKED) km = (k0 + 8 * aq < P.Cin) ? a_okR : 0u;
     const int cc = (bn ? k0 : 0) + 8 * aq;
     const float4 a0 = *reinterpret_cast<const float4*>(sAB + cc);
     const float4 a1 = *reinterpret_cast<const float4*>(sAB + cc + 4);
@@ -199,7 +208,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) boff[nt] = (nt * 32 + l31) * KCP + 8 * lh;
 
-  auto mfma_block = [&]() {
+  // WITH_LOADS: the next chunk's 15 global loads go out one per k-step behind that step's MFMAs.  Issued as one
+  // burst in front of the block they held the wave for 1800-2000 cycles before its first MFMA (stamps): the texture
+  // path takes the 60 KB of a group at 64 B/clk.
+  auto mfma_block = [&](auto Lc) {
+    (void)Lc;
     bf16x8 af[2][2], bfr[2][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
   };
 
   // ---- prologue: first chunk on its way, BN coefficients into LDS ----------------------------------------------
-  if (K > 0) { setup_tile(); load_chunk(); advance_load(); }
+  if (K > 0) { setup_tile(); load_chunk(); advance_load(); }   // chunk 0 -> registers
   if (has_bn) {
     for (int c = tid; c < P.C0; c += Cfg::NT) { sAB[c] = P.a0[c]; sAB[1024 + c] = P.b0[c]; }
   }
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
   // Both groups run the same loop -- stage chunk k, barrier, multiply chunk k, barrier -- group 1 one barrier late:
   // that one-phase offset is the whole ping-pong (group 0 multiplies while group 1 stages and vice versa).
 #ifdef FU_CONV_STAMPS
-  unsigned long long tS = 0, tB1 = 0, tM = 0, tB2 = 0, t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tS = 0, tB1 = 0, tM = 0, tB2 = 0, tPre = 0, t0 = __builtin_amdgcn_s_memtime();
 #endif
   if (grp == 1) __syncthreads();
   for (int k = 0; k < Kmax + 2; ++k) {
@@ -337,8 +350,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
     // ---- staging phase: S(k) first (it frees the staging registers), then the epilogue of the tile that M(k - 1)
     //      completed
     if (k < K) {
-      if (borderS || chS * KC + KC > P.Cin) store_chunk(std::true_type{});
+      if (borderR || chR * KC + KC > P.Cin) store_chunk(std::true_type{});
       else store_chunk(std::false_type{});
+      jM = jR; chM = chR;
+      // The registers are free again: the NEXT chunk's loads go out now, in this group's staging phase, and have the
+      // whole MFMA phase to land (measured: >= 3500 cycles from issue to data under load; issued as a burst in front of
+      // the MFMA block they cost the wave 1800-2000 cycles of issue time before its first MFMA, spread inside the block
+      // they arrived too late for the next staging phase).  Always issued (past the end: a harmless extra chunk).
+      load_chunk();
+      advance_load();
     }
     if (epi_pending) {
       const bool full = (tc.y0 + TH <= P.H) && (tc.x0 + TW <= P.W) && (tc.n0 + BN <= P.N);
@@ -358,8 +378,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
     // ---- MFMA phase: statistics of the tile whose epilogue just ran, loads of chunk k + 1, M(k)
     flush_stats();
     if (k < K) {
-      if (chS == nChunks - 1) {           // M(k) completes a tile: keep its coordinates, fetch its bias
-        tc = decode(jL - (chL == 0 ? 1 : 0));
+      if (chM == nChunks - 1) {           // M(k) completes a tile: keep its coordinates, fetch its bias
+        tc = decode(jM);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           const int n = tc.n0 + nt * 32 + l31;
@@ -367,8 +387,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
         }
         epi_pending = true;
       }
-      if (k + 1 < K) { load_chunk(); advance_load(); }   // raw loads stay in flight under the MFMA block
-      mfma_block();
+#ifdef FU_CONV_STAMPS
+      const unsigned long long tpre = __builtin_amdgcn_s_memtime();
+      if (k >= 2 && k < K - 1) tPre += tpre - tc0;
+#endif
+      mfma_block(std::false_type{});
     }
 #ifdef FU_CONV_STAMPS
     const unsigned long long td = __builtin_amdgcn_s_memtime();
@@ -383,7 +406,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P, int nTiles) {
 #ifdef FU_CONV_STAMPS
   if (P.dbg && (tid & 255) == 0) {
     unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 2 + grp) * 8;
-    d[0] = tS; d[1] = tB1; d[2] = tM; d[3] = tB2; d[4] = (unsigned long long)max(K - 3, 0); d[5] = __builtin_amdgcn_s_memtime() - t0;
+    d[0] = tS; d[1] = tB1; d[2] = tM; d[3] = tB2; d[4] = (unsigned long long)max(K - 3, 0); d[5] = __builtin_amdgcn_s_memtime() - t0; d[6] = tPre;
   }
 #endif
 }

@@ -19,7 +19,7 @@ def run(B, C0, Cout, H, W):
     for g in (0, 1):
         r = d[g::2]; r = r[r[:, 4] > 0]
         n = r[:, 4]
-        print(f"{C0}->{Cout}@{H} group {g}: per iteration: staging {np.median(r[:,0]/n):.0f} | barrier {np.median(r[:,1]/n):.0f} | mfma part {np.median(r[:,2]/n):.0f} | barrier {np.median(r[:,3]/n):.0f} | lifetime {np.median(r[:,5]):.0f}")
+        print(f"{C0}->{Cout}@{H} group {g}: per iteration: staging {np.median(r[:,0]/n):.0f} | barrier {np.median(r[:,1]/n):.0f} | mfma part {np.median(r[:,2]/n):.0f} (of which before the MFMA block {np.median(r[:,6]/n):.0f}) | barrier {np.median(r[:,3]/n):.0f} | lifetime {np.median(r[:,5]):.0f}")
 run(16, 512, 512, 32, 32)
 run(16, 128, 128, 128, 128)
 run(16, 64, 64, 256, 256)
