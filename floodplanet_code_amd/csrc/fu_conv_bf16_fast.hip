@@ -15,6 +15,13 @@
 // D0 % BN == 0, every tensor < 2 GiB.  Everything else (and only that) runs on the general kernel.
 #include "fu_conv_bf16.h"
 
+#ifndef FU_FAST_LOADS_PER_STEP
+#define FU_FAST_LOADS_PER_STEP 2   // the next chunk's 15 global loads go out 2 per k-step behind that step's MFMAs: as one
+#endif                             // burst in front of the block they hold the wave ~1900 cycles before its first MFMA
+                                   // (texture path: 60 KB per workgroup at 64 B/clk); measured 787 -> 817 TF (0 = burst).
+#ifndef FU_FAST_FRAG_DIST           // Raising the MFMA waves' priority (s_setprio) was measured too: no gain.
+#define FU_FAST_FRAG_DIST 1        // k-steps of fragment prefetch (1: two register buffers, 2: three)
+#endif
 #ifndef FU_FAST_DBG
 #define FU_FAST_DBG 0   // diagnostic builds (make EXTRA=-DFU_FAST_DBG=4): 4 = epilogue without its global stores
 #endif                  // (64->64 @256^2: 114.8 -> 92.2 us).  -DFU_CONV_STAMPS: s_memtime stamps for
@@ -98,23 +105,32 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   uint4 ra[A_ITERS];
   uint4 rw[W_ITERS];
 
-  auto load_chunk = [&](int k0) {
+  // chunk k0 -> staging registers: uniform bases once (load_begin), then one 16-byte load per slot
+  const char* abL = nullptr;
+  const char* wbL = nullptr;
+  unsigned cmL = 0, woL = 0;
+  auto load_begin = [&](int k0) {
     const bool s1 = P.src1 != nullptr && k0 >= P.C0;           // uniform: C0 % 32 == 0 when there is a second source
-    const char* ab = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
-                        : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
-    const char* wb = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
+    abL = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
+             : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
+    wbL = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
     // ragged last chunk (Cin % 32 != 0): octets past Cin load offset 0 and are zeroed on the A side
-    const unsigned cm = (k0 + 8 * aq < P.Cin) ? 0xffffffffu : 0u;
-    static_for<0, A_ITERS>([&](auto I) {
-      constexpr int it = decltype(I)::value;
-      ra[it] = *reinterpret_cast<const uint4*>(ab + (a_off[it] & cm));
-    });
-    const unsigned wo = w_off & cm;
-    static_for<0, W_ITERS>([&](auto I) {
-      constexpr int it = decltype(I)::value;
+    cmL = (k0 + 8 * aq < P.Cin) ? 0xffffffffu : 0u;
+    woL = w_off & cmL;
+  };
+  auto load_slot = [&](auto Sc) {
+    constexpr int sl = decltype(Sc)::value;
+    if constexpr (sl < A_ITERS) {
+      ra[sl] = *reinterpret_cast<const uint4*>(abL + (a_off[sl] & cmL));
+    } else if constexpr (sl < A_ITERS + W_ITERS) {
+      constexpr int it = sl - A_ITERS;
       if (it < Cfg::W_FULL || wm < Cfg::W_REM / 64)
-        rw[it] = *reinterpret_cast<const uint4*>(wb + (wo + (unsigned)it * w_step));
-    });
+        rw[it] = *reinterpret_cast<const uint4*>(wbL + (woL + (unsigned)it * w_step));
+    }
+  };
+  auto load_chunk = [&](int k0) {
+    load_begin(k0);
+    static_for<0, A_ITERS + W_ITERS>([&](auto Sc) { load_slot(Sc); });
   };
 
   auto store_chunk = [&](int k0, auto Mc) {
@@ -192,8 +208,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 #endif
   // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
   // s+1 are requested from LDS before the MFMAs of step s are issued.
-  auto mfma_block = [&]() {
-    bf16x8 af[2][2], bfr[2][NTW];
+  auto mfma_block = [&](auto Lc) {
+    constexpr int LOADS = decltype(Lc)::value;   // 0: none; n: next chunk's loads, n per k-step behind its MFMAs
+    constexpr int FD = FU_FAST_FRAG_DIST, NB = FD + 1;
+    bf16x8 af[NB][2], bfr[NB][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
       constexpr int tap = st >> 1, ks = st & 1;
@@ -204,11 +222,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
       for (int nt = 0; nt < NTW; ++nt)
         bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
     };
-    load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<0, FD>([&](auto Sc) { load_frags(Sc, std::integral_constant<int, decltype(Sc)::value % NB>{}); });
     static_for<0, 18>([&](auto S) {
-      constexpr int st = decltype(S)::value, buf = st & 1;
-      if constexpr (st + 1 < 18) {
-        load_frags(std::integral_constant<int, st + 1>{}, std::integral_constant<int, buf ^ 1>{});
+      constexpr int st = decltype(S)::value, buf = st % NB;
+      if constexpr (st + FD < 18) {
+        load_frags(std::integral_constant<int, st + FD>{}, std::integral_constant<int, (st + FD) % NB>{});
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
       }
 #pragma unroll
@@ -216,6 +234,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
+      if constexpr (LOADS > 0)
+        static_for<0, LOADS>([&](auto J) {
+          constexpr int sl = st * LOADS + decltype(J)::value;
+          if constexpr (sl < A_ITERS + W_ITERS) load_slot(std::integral_constant<int, sl>{});
+        });
     });
   };
   auto stage = [&](int k0) {
@@ -235,14 +258,19 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     if (ch == 0) T1 = __builtin_amdgcn_s_memtime();
 #endif
     if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // next chunk starts the second source
+#if FU_FAST_LOADS_PER_STEP > 0
+    load_begin(k0 + KC);
+    mfma_block(std::integral_constant<int, FU_FAST_LOADS_PER_STEP>{});
+#else
     load_chunk(k0 + KC);                                      // raw loads stay in flight under the MFMA block
-    mfma_block();
+    mfma_block(std::integral_constant<int, 0>{});
+#endif
   }
   stage((nChunks - 1) * KC);
 #ifdef FU_CONV_STAMPS
   if (nChunks == 1) T1 = __builtin_amdgcn_s_memtime();
 #endif
-  mfma_block();
+  mfma_block(std::integral_constant<int, 0>{});
 #ifdef FU_CONV_STAMPS
   T2 = __builtin_amdgcn_s_memtime();
 #endif
