@@ -22,6 +22,9 @@
 #ifndef FU_FAST_FRAG_DIST           // Raising the MFMA waves' priority (s_setprio) was measured too: no gain.
 #define FU_FAST_FRAG_DIST 1        // k-steps of fragment prefetch (1: two register buffers, 2: three)
 #endif
+#ifndef FU_FAST_STORE16
+#define FU_FAST_STORE16 1   // interior tiles: 16-byte epilogue stores (0: the 8-byte form); measured 825 -> 858 TF
+#endif
 #ifndef FU_FAST_DBG
 #define FU_FAST_DBG 0   // diagnostic builds (make EXTRA=-DFU_FAST_DBG=4): 4 = epilogue without its global stores
 #endif                  // (64->64 @256^2: 114.8 -> 92.2 us).  -DFU_CONV_STAMPS: s_memtime stamps for
@@ -351,10 +354,81 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
       ssq[nt] = q2.x + q2.y;
     }
   };
+#if FU_FAST_STORE16
+  // Interior tiles: 16-byte stores.  Three exchange levels inside every group of 8 lanes (xor 1 and xor 2 inside the
+  // quads as above, then quad <-> quad through row_shl:4 / row_shr:4 with bank masks) turn 8 accumulator registers
+  // (8 pixels x 1 channel per lane) into 8 channels of ONE pixel per lane: half the store instructions of the 8-byte
+  // form (the epilogue is store-issue bound on the shallow layers).
+  auto epilogue16 = [&](auto Bc) {
+    constexpr bool BIAS = decltype(Bc)::value;
+    const int li = lane & 7;
+    const bool upper = (li & 4) != 0;
+    unsigned sb16[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = (li & 3) + 8 * (li >> 2) + 4 * lh;
+        const int oy = y0 + (wm * 2 + mt) * 2 + h;
+        const int ox = x0 + (h ? ((col - (HWd & 15)) & 15) : col);
+        sb16[mt][h] = ((unsigned)((bb * P.H + oy) * P.W + ox) * (unsigned)dstride + (unsigned)(l31 & ~7)) * 2u;
+      }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const f32x2 bias2 = {biasv[nt], biasv[nt]};
+      f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          unsigned E[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            f32x2 a = {acc[mt][nt][8 * h + 2 * t], acc[mt][nt][8 * h + 2 * t + 1]};
+            s2 += a;
+            q2 = a * a + q2;
+            if constexpr (BIAS) a += bias2;
+            const unsigned pk = pack_bf16x2(a);
+            const unsigned rv = (unsigned)__builtin_amdgcn_mov_dpp((int)pk, 0xB1, 0xF, 0xF, true);   // quad xor 1
+            E[t] = __builtin_amdgcn_perm(rv, pk, sel1);      // even lane: pixel 2t, odd lane: pixel 2t + 1 (channel pair)
+          }
+          unsigned F[2][2];                                  // F[u]: 4 channels of pixel 4u + (lane & 3)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const unsigned send = q_lo ? E[2 * u + 1] : E[2 * u];
+            const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);   // quad xor 2
+            F[u][0] = q_lo ? E[2 * u] : recv;
+            F[u][1] = q_lo ? recv : E[2 * u + 1];
+          }
+          unsigned R[2];                                     // the partner quad's half of this lane's pixel
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const unsigned send = upper ? F[0][d] : F[1][d];
+            const int r1 = __builtin_amdgcn_update_dpp((int)send, (int)send, 0x104, 0xF, 0x5, false);   // row_shl:4 -> lower quads
+            R[d] = (unsigned)__builtin_amdgcn_update_dpp(r1, (int)send, 0x114, 0xF, 0xA, false);        // row_shr:4 -> upper quads
+          }
+          uint4 o;
+          o.x = upper ? R[0] : F[0][0];
+          o.y = upper ? R[1] : F[0][1];
+          o.z = upper ? F[1][0] : R[0];
+          o.w = upper ? F[1][1] : R[1];
+          *reinterpret_cast<uint4*>(dbase + sb16[mt][h] + nt * 64) = o;
+        }
+      }
+      ssum[nt] = s2.x + s2.y;
+      ssq[nt] = q2.x + q2.y;
+    }
+  };
+#endif
   const bool full = (y0 + TH <= P.H) && (x0 + TW <= P.W) && (n0 + BN <= P.N);   // workgroup-uniform
   if (full) {
+#if FU_FAST_STORE16
+    if (P.bias) epilogue16(std::true_type{});
+    else epilogue16(std::false_type{});
+#else
     if (P.bias) epilogue(std::true_type{}, std::true_type{});
     else epilogue(std::true_type{}, std::false_type{});
+#endif
   } else {
     if (P.bias) epilogue(std::false_type{}, std::true_type{});
     else epilogue(std::false_type{}, std::false_type{});
