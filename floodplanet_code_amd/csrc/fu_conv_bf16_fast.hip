@@ -25,6 +25,9 @@
 #ifndef FU_FAST_STORE16
 #define FU_FAST_STORE16 1   // interior tiles: 16-byte epilogue stores (0: the 8-byte form); measured 825 -> 858 TF
 #endif
+#ifndef FU_FAST_ROWPERM
+#define FU_FAST_ROWPERM 1
+#endif
 #ifndef FU_FAST_DBG
 #define FU_FAST_DBG 0   // diagnostic builds (make EXTRA=-DFU_FAST_DBG=4): 4 = epilogue without its global stores
 #endif                  // (64->64 @256^2: 114.8 -> 92.2 us).  -DFU_CONV_STAMPS: s_memtime stamps for
@@ -80,13 +83,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   //      a_off = byte offset of that unit inside the CURRENT source at channel 0 (recomputed once, at the switch to
   //      the second source); out-of-image pixels load the nearest image pixel and are zeroed when written to LDS.
   const int aq = tid & 3;
+  // LDS row of this thread's staging units.  A ds_write_b128 is served in groups of 8 lanes = 2 rows x 4 units; with
+  // 80-byte rows, consecutive rows (20 dwords apart) put unit 3 of one row on the banks of unit 0 of the next (2-way
+  // conflict on every write: ~20 % of the LDS-active cycles, profiles/r1_pmc_bf16.json).  Rows 4 apart (80 dwords = 16 mod
+  // 32) do not collide, so the two rows of a group are r and r + 4: bits 0 and 2 of the row index are swapped.
+#if FU_FAST_ROWPERM
+  const int srow_lin = tid >> 2;
+  const int srow = (srow_lin & ~7) | ((srow_lin & 1) << 2) | ((srow_lin >> 1) & 3);
+#else
+  const int srow = tid >> 2;
+#endif
   unsigned a_off[A_ITERS];
   unsigned a_ok = 0;
   auto setup_a = [&](int Cs) {
     a_ok = 0;
     static_for<0, A_ITERS>([&](auto I) {
       constexpr int it = decltype(I)::value;
-      const int hp = (tid >> 2) + it * RPI;
+      const int hp = srow + it * RPI;
       const int hy = (hp * 3641) >> 16;                          // hp / 18 (exact for hp < 65536)
       const int hx = hp - hy * HWd;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   setup_a(P.C0);
   // weights [tap][n][Cin]: row r = (t >> 2) + 64 it  ->  tap = r / BN, n = n0 + r % BN; the per-iteration part of the
   // address is uniform.  Rows past N load row 0 (their output columns are never stored).
-  const int wrow = tid >> 2;
+  const int wrow = srow;
   const int wco = wrow & (BN - 1), wtsub = wrow / BN;
   const bool w_ok = n0 + wco < P.N;
   const unsigned w_off = (w_ok ? (unsigned)((wtsub * P.N + n0 + wco) * P.Cin) * 2u : 0u) + 16u * aq;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     const f32x2 cb0 = {b0.x, b0.y}, cb1 = {b0.z, b0.w}, cb2 = {b1.x, b1.y}, cb3 = {b1.z, b1.w};
     static_for<0, A_ITERS>([&](auto I) {
       constexpr int it = decltype(I)::value;
-      if (it < Cfg::A_FULL || tid < Cfg::A_REM) {
+      if (it < Cfg::A_FULL || srow + it * RPI < NHP) {
         unsigned x = ra[it].x, y = ra[it].y, z = ra[it].z, w = ra[it].w;
         if (bn) {
           x = bn_relu_pair(x, ca0, cb0); y = bn_relu_pair(y, ca1, cb1);
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
           const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)km, it, 1);   // bit it -> 0 / 0xffffffff
           x &= m; y &= m; z &= m; w &= m;
         }
-        *reinterpret_cast<uint4*>(sA + ((tid >> 2) + it * RPI) * KCP + 8 * aq) = make_uint4(x, y, z, w);
+        *reinterpret_cast<uint4*>(sA + (srow + it * RPI) * KCP + 8 * aq) = make_uint4(x, y, z, w);
       }
     });
     static_for<0, W_ITERS>([&](auto I) {
