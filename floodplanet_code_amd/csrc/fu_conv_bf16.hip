@@ -408,6 +408,7 @@ struct BWgP {
   const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0; const bf16_t* dy;
   float* slab;
   int C0, C1, Cin, Cout, B, H, W, tilesX, tilesY, nPix, nCi, nCo, S, perSplit;
+  unsigned long long* dbg;   // FU_CONV_STAMPS builds: per-workgroup phase sums (tools/stamp_wgrad.py)
 };
 
 // Two transposing reads -> one MFMA fragment.  NOTE (hipcc / ROCm 7.2): the v4i16 form of the builtin followed by
@@ -552,12 +553,27 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
 
   const int pt0 = split * P.perSplit;
   const int pt1 = min(P.nPix, pt0 + P.perSplit);
+#ifdef FU_CONV_STAMPS
+  unsigned long long tStage = 0, tIssue = 0, tMfma = 0, tA = __builtin_amdgcn_s_memtime(), tStart = tA;
+#endif
   if (pt0 < pt1) load_tile(pt0);
   for (int pt = pt0; pt < pt1; ++pt) {
+#ifdef FU_CONV_STAMPS
+    tA = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();            // previous stage's fragment reads are done (sAB visible on the first pass)
     store_tile();
     __syncthreads();
-    if (pt + 1 < pt1) load_tile(pt + 1);   // in flight under the MFMA block
+#ifdef FU_CONV_STAMPS
+    const unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
+    // in flight under the MFMA block.  ALWAYS issued (the last stage re-reads its own tile): under `if (pt + 1 < pt1)`
+    // the staging registers are phis of a loaded and a not-loaded path, hipcc copies some of them right behind the
+    // loads and waits for them (vmcnt) in front of the MFMA block -- with one workgroup per CU nothing covers that
+    load_tile(min(pt + 1, pt1 - 1));
+#ifdef FU_CONV_STAMPS
+    const unsigned long long tC = __builtin_amdgcn_s_memtime();
+#endif
     // Walk the halo rows once: the X fragment of (halo row hr, column shift dx) feeds up to three taps
     // (dy = 0..2 with pixel row r = hr - dy), so every fragment is fetched from LDS once; dy fragments of the last
     // three pixel rows stay in a 4-deep register ring.  Next step's fragment is requested before this step's MFMAs.
@@ -585,7 +601,14 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
           acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
       });
     });
+#ifdef FU_CONV_STAMPS
+    const unsigned long long tD = __builtin_amdgcn_s_memtime();
+    if (pt > pt0) { tStage += tB - tA; tIssue += tC - tB; tMfma += tD - tC; }
+#endif
   }
+#ifdef FU_CONV_STAMPS
+  const unsigned long long tE = __builtin_amdgcn_s_memtime();
+#endif
   const int co = co0 + ni * 32 + l31;
   if (co < P.Cout) {
 #pragma unroll
@@ -597,6 +620,14 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
       }
     }
   }
+#ifdef FU_CONV_STAMPS
+  if (P.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* d = P.dbg + (size_t)blockIdx.x * 8;
+    d[0] = tStage; d[1] = tIssue; d[2] = tMfma; d[3] = (unsigned long long)max(pt1 - pt0 - 1, 0);
+    d[4] = __builtin_amdgcn_s_memtime() - tE; d[5] = __builtin_amdgcn_s_memtime() - tStart;
+  }
+#endif
 }
 
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
@@ -648,6 +679,7 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   P.src0 = (const bf16_t*)in.src0; P.src1 = (const bf16_t*)in.src1; P.a0 = in.a0; P.b0 = in.b0; P.dy = dy;
   P.slab = slab;
   P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.Cout = Cout; P.B = B; P.H = H; P.W = W;
+  P.dbg = g_conv_dbg;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0 && Cout % 8 == 0, "wgrad_bf16: channel counts must be multiples of 8");
   int st;
   if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU

@@ -1,0 +1,23 @@
+"""Per-phase s_memtime breakdown of k_wgrad_bf16 (library built with `make EXTRA=-DFU_CONV_STAMPS`)."""
+import sys, ctypes as C, torch, numpy as np
+sys.path.insert(0, '.')
+from floodplanet_code_amd import _lib
+from floodplanet_code_amd._lib import check, ptr
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH); raw.fu_debug_set_conv_stamps.argtypes = [C.c_void_p]
+DEV = 'cuda:0'
+def run(B, C0, Cout, H, W):
+    x = torch.randn(B, H, W, C0, device=DEV).to(torch.bfloat16); a = torch.rand(C0, device=DEV) + 0.5; b = torch.randn(C0, device=DEV) * 0.1
+    dy = torch.randn(B, H, W, Cout, device=DEV).to(torch.bfloat16)
+    dw = torch.empty(Cout, C0, 3, 3, device=DEV)
+    dbg = torch.zeros(4096 * 8, dtype=torch.int64, device=DEV)
+    for it in range(3):
+        raw.fu_debug_set_conv_stamps(dbg.data_ptr() if it == 2 else None)
+        check(lib.fu_op_conv3x3_wgrad(1, ptr(x), C0, ptr(a), ptr(b), None, 0, ptr(dy), Cout, ptr(dw), B, H, W, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize(); raw.fu_debug_set_conv_stamps(None)
+    d = dbg.view(4096, 8).cpu().numpy().astype(np.float64)
+    d = d[d[:, 3] > 0]; n = d[:, 3]
+    print(f"{C0}->{Cout}@{H}: wgs {len(d)} stages/wg {np.median(n)+1:.0f} | per stage: wait+stage+barriers {np.median(d[:,0]/n):.0f} | load issue {np.median(d[:,1]/n):.0f} | mfma {np.median(d[:,2]/n):.0f} || epilogue+drain {np.median(d[:,4]):.0f} | lifetime {np.median(d[:,5]):.0f}")
+run(16, 64, 64, 256, 256)
+run(16, 128, 128, 128, 128)
+run(16, 512, 512, 32, 32)
