@@ -10,6 +10,7 @@
 //                packed per-tap copies (forward and tap-reversed dgrad layouts) refreshed after each update.
 #include "../../include/floodunet.h"
 #include "fu_common.h"
+#include <stdlib.h>
 
 #include <math.h>
 #include <string.h>
@@ -264,6 +265,12 @@ struct fu_ctx {
   float* stats = nullptr;
   float* bnb_part = nullptr;
   float* db_part = nullptr;
+  float* db_part2 = nullptr;      // second bias-gradient partial buffer (side-stream wgrad, alternating per conv)
+  hipStream_t side = nullptr;     // side stream for the weight-gradient chain (wgrad + slab reduce + transpose)
+  hipEvent_t ev_gy = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_blk = nullptr;
+  int wg_parity = 0;
+  bool side_on = true;            // fu_set_side_stream
+  bool wg_pending[2] = {false, false};
   double* dscratch = nullptr;
   fu::SyncDesc sync;           // exact data-parallel mode (fu_set_exact_sync); hook == nullptr: off
   float* slab = nullptr;
@@ -470,6 +477,7 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->stats, max_stats * sizeof(float));
   A.want(&c->bnb_part, max_bnb * sizeof(float));
   A.want(&c->db_part, max_dbp * sizeof(float));
+  A.want(&c->db_part2, max_dbp * sizeof(float));
   A.want(&c->dscratch, reduce_scratch_elems(std::max(max_c, 64)) * sizeof(double));
   A.want(&c->slab, max_slab * sizeof(float));
   A.want(&c->ce_part, 2 * 1024 * sizeof(float));
@@ -625,14 +633,34 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
   int ndb = 0;
   // BN + ReLU backward: gy <- dL/dy ; dgamma, dbeta
+  // The weight-gradient chain of this conv (wgrad, slab reduce, transpose) depends only on gy and on saved activations
+  // and nothing in the rest of backward depends on it: it runs on a side stream, concurrently with this conv's dgrad
+  // and the next BN backward (its 8-wave workgroups spend more than half of every stage staging with the MFMA pipe
+  // idle, tools/stamp_wgrad.py; the dgrad workgroups that fit beside them on a CU use it).  db partials alternate
+  // between two buffers so that the main stream only has to wait for the wgrad of two convs ago.
+  const bool side = c->side != nullptr && c->side_on;
+  const int par = c->wg_parity;
+  float* dbp = (side && par) ? c->db_part2 : c->db_part;
+  if (side && c->wg_pending[par]) FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_wg[par], 0));   // buffer free again
   FU_TRY(launch_bn_bwd(c->prec, v.gy, v.y, v.cout, npix, v.a, v.b, v.mean, v.invstd, P(c, v.p_g), G(c, v.p_g),
-                       G(c, v.p_beta), c->bnb_part, v.coef, c->db_part, &ndb, c->dscratch, s));
+                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s));
   // weight (and bias) gradient
   const ConvIn in = conv_input(c, i, j);
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
+  hipStream_t ws = s;
+  if (side) {
+    FU_HIP_CHECK(hipEventRecord(c->ev_gy, s));
+    FU_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_gy, 0));
+    ws = c->side;
+  }
   prof_arm(c, FU_K_WGRAD, fl);
-  FU_TRY(launch_conv3x3_wgrad(c->prec, in, v.gy, v.cout, c->slab, G(c, v.p_w), v.cin_real, c->db_part, ndb,
-                              G(c, v.p_b), B, H, W, s));
+  FU_TRY(launch_conv3x3_wgrad(c->prec, in, v.gy, v.cout, c->slab, G(c, v.p_w), v.cin_real, dbp, ndb,
+                              G(c, v.p_b), B, H, W, ws));
+  if (side) {
+    FU_HIP_CHECK(hipEventRecord(c->ev_wg[par], c->side));
+    c->wg_pending[par] = true;
+    c->wg_parity ^= 1;
+  }
   // data gradient
   if (!(i == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
   if (j == 1) {
@@ -671,7 +699,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   return 0;
 }
 
-int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStream_t s) {
+int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStream_t s, bool join) {
   const fu_config& f = c->cfg;
   const int B = c->last_batch;
   if (block == 0) {
@@ -687,6 +715,11 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
   const int i = 9 - block;
   FU_TRY(backward_conv(c, i, 1, B, s));
   FU_TRY(backward_conv(c, i, 0, B, s));
+  if (c->side && c->side_on && join) {   // the block's gradients are complete (for the caller's all-reduce / Adam) once the side stream is
+    FU_HIP_CHECK(hipEventRecord(c->ev_blk, c->side));
+    FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_blk, 0));
+    c->wg_pending[0] = c->wg_pending[1] = false;
+  }
   return 0;
 }
 
@@ -748,6 +781,18 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   c->esize = c->prec == PREC_F32 ? 4 : 2;
   int st = build_plan(c);
   if (st == 0) st = alloc_workspace(c);
+  // side stream for the weight-gradient chain (bilinear nets; the ConvTranspose variant shares the slab with its own
+  // wgrad on the main stream).  FU_NO_SIDE_STREAM=1 keeps everything on the caller's stream.
+  if (st == 0 && c->cfg.bilinear && !getenv("FU_NO_SIDE_STREAM")) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+    if (c->side) {
+      bool ok = hipEventCreateWithFlags(&c->ev_gy, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_wg[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_wg[1], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_blk, hipEventDisableTiming) == hipSuccess;
+      if (!ok) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+    }
+  }
   if (st != 0) { fu_destroy(c); return st; }
   *out = c;
   return FU_OK;
@@ -758,6 +803,10 @@ int fu_destroy(fu_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+  if (c->side) {
+    (void)hipStreamDestroy(c->side);
+    for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk}) if (e) (void)hipEventDestroy(e);
+  }
   if (c->arena.base) (void)hipFree(c->arena.base);
   for (void* p : c->extra_allocs) (void)hipFree(p);
   delete c;
@@ -867,11 +916,25 @@ int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stre
   }
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
   SyncScope sc(c, true);
-  return backward_block_impl(c, block, dlogits, (hipStream_t)stream);
+  return backward_block_impl(c, block, dlogits, (hipStream_t)stream, true);
+}
+
+int fu_set_side_stream(fu_ctx* c, int enable) {
+  FU_REQUIRE(c, "null context");
+  c->side_on = enable != 0;
+  return FU_OK;
 }
 
 int fu_backward(fu_ctx* c, const float* dlogits, fu_stream stream) {
-  for (int b = 0; b < 10; ++b) FU_TRY(fu_backward_block(c, b, dlogits, stream));
+  FU_REQUIRE(c, "null context");
+  if (!(c->last_batch > 0 && c->fwd_training)) {
+    set_error("fu_backward: the last fu_forward was not a training forward");
+    return FU_ERR_STATE;
+  }
+  FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
+  SyncScope sc(c, true);
+  // whole backward: the side stream (weight gradients) is joined once, after the last block
+  for (int b = 0; b < 10; ++b) FU_TRY(backward_block_impl(c, b, dlogits, (hipStream_t)stream, b == 9));
   return FU_OK;
 }
 

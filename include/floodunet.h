@@ -126,6 +126,13 @@ int fu_loss_bce_dice(fu_ctx* ctx, const int64_t* target, int ignore_index, float
  * the logits, or NULL to use the gradient of the last fu_loss_* call.  Gradients are written
  * (not accumulated) into the bound flat gradient buffer. */
 int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
+/* The weight-gradient chain of every conv (wgrad, slab reduce, transpose) runs on a context-owned side stream,
+ * concurrently with the data-gradient / BatchNorm-backward chain on the caller's stream; fu_backward joins the two
+ * before it returns its work to the caller's stream order, fu_backward_block at the end of every block (the block's
+ * gradients are then final for a bucketed all-reduce).  enable = 0 keeps everything on the caller's stream (the
+ * default when the environment variable FU_NO_SIDE_STREAM is set at fu_create, and for bilinear = 0). */
+int fu_set_side_stream(fu_ctx* ctx, int enable);
+
 /* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
  * 9 = inc.  After block k returns, the gradient range fu_block_param_range(k) is final on `stream`. */
 int fu_num_blocks(const fu_ctx* ctx);
