@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
                     help="bf16 = BASELINE.json configs[1] (default); f32 = the 1e-4 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-pass", action="store_true",
+                    help="skip the extra un-timed pass that measures the dominant kernel without the side stream")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
@@ -173,7 +175,7 @@ def main():
     # event-timed durations in the timed region include that sharing.  A short extra pass with the side stream off
     # (fu_set_side_stream) gives the same kernel's un-shared rate as `achieved_serial` (not part of `value`).
     serial = None
-    if best and world == 1:
+    if best and world == 1 and not args.no_serial_pass:
         _lib.check(lib.fu_set_side_stream(net._ctx, 0))
         trainer.step(x, target, 0)
         _lib.check(lib.fu_profile_enable(net._ctx, 1))

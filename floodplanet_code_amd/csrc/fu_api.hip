@@ -783,7 +783,9 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   if (st == 0) st = alloc_workspace(c);
   // side stream for the weight-gradient chain (bilinear nets; the ConvTranspose variant shares the slab with its own
   // wgrad on the main stream).  FU_NO_SIDE_STREAM=1 keeps everything on the caller's stream.
-  if (st == 0 && c->cfg.bilinear && !getenv("FU_NO_SIDE_STREAM")) {
+  // (bf16 only: in fp32 mode the concurrency changes nothing in the step time -- both kernels are MFMA bound at 0.7 of
+  //  the fp32 peak -- and only inflates the per-launch durations of the parity build)
+  if (st == 0 && c->cfg.bilinear && c->prec != fu::PREC_F32 && !getenv("FU_NO_SIDE_STREAM")) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
     if (c->side) {
       bool ok = hipEventCreateWithFlags(&c->ev_gy, hipEventDisableTiming) == hipSuccess &&

@@ -130,7 +130,7 @@ int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
  * concurrently with the data-gradient / BatchNorm-backward chain on the caller's stream; fu_backward joins the two
  * before it returns its work to the caller's stream order, fu_backward_block at the end of every block (the block's
  * gradients are then final for a bucketed all-reduce).  enable = 0 keeps everything on the caller's stream (the
- * default when the environment variable FU_NO_SIDE_STREAM is set at fu_create, and for bilinear = 0). */
+ * default when the environment variable FU_NO_SIDE_STREAM is set at fu_create, for bilinear = 0 and in fp32 mode). */
 int fu_set_side_stream(fu_ctx* ctx, int enable);
 
 /* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
