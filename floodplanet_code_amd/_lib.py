@@ -77,6 +77,7 @@ SIGNATURES = {
     "fu_profile_enable": (_i, [_p, _i]),
     "fu_test_force_general_conv": (None, [_i]),
     "fu_set_side_stream": (_i, [_p, _i]),
+    "fu_backward_join": (_i, [_p, _p]),
     "fu_set_exact_sync": (_i, [_p, SYNC_HOOK, _p, _i, _p, _i64]),
     "fu_exact_sync_bytes": (_i64, [_p]),
     "fu_profile_read": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -269,7 +269,7 @@ struct fu_ctx {
   hipStream_t side = nullptr;     // side stream for the weight-gradient chain (wgrad + slab reduce + transpose)
   hipEvent_t ev_gy = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_blk = nullptr;
   int wg_parity = 0;
-  bool side_on = true;            // fu_set_side_stream
+  int side_mode = 1;              // fu_set_side_stream: 0 off, 1 on (blocks join), 2 on (the caller joins: fu_backward_join)
   bool wg_pending[2] = {false, false};
   double* dscratch = nullptr;
   fu::SyncDesc sync;           // exact data-parallel mode (fu_set_exact_sync); hook == nullptr: off
@@ -638,7 +638,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   // and the next BN backward (its 8-wave workgroups spend more than half of every stage staging with the MFMA pipe
   // idle, tools/stamp_wgrad.py; the dgrad workgroups that fit beside them on a CU use it).  db partials alternate
   // between two buffers so that the main stream only has to wait for the wgrad of two convs ago.
-  const bool side = c->side != nullptr && c->side_on;
+  const bool side = c->side != nullptr && c->side_mode != 0;
   const int par = c->wg_parity;
   float* dbp = (side && par) ? c->db_part2 : c->db_part;
   if (side && c->wg_pending[par]) FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_wg[par], 0));   // buffer free again
@@ -715,7 +715,7 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
   const int i = 9 - block;
   FU_TRY(backward_conv(c, i, 1, B, s));
   FU_TRY(backward_conv(c, i, 0, B, s));
-  if (c->side && c->side_on && join) {   // the block's gradients are complete (for the caller's all-reduce / Adam) once the side stream is
+  if (c->side && c->side_mode != 0 && join) {   // the block's gradients are complete (for the caller's all-reduce / Adam) once the side stream is
     FU_HIP_CHECK(hipEventRecord(c->ev_blk, c->side));
     FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_blk, 0));
     c->wg_pending[0] = c->wg_pending[1] = false;
@@ -918,12 +918,22 @@ int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stre
   }
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
   SyncScope sc(c, true);
-  return backward_block_impl(c, block, dlogits, (hipStream_t)stream, true);
+  return backward_block_impl(c, block, dlogits, (hipStream_t)stream, c->side_mode != 2);
 }
 
-int fu_set_side_stream(fu_ctx* c, int enable) {
+int fu_set_side_stream(fu_ctx* c, int mode) {
+  FU_REQUIRE(c && mode >= 0 && mode <= 2, "fu_set_side_stream: mode must be 0, 1 or 2");
+  c->side_mode = mode;
+  return FU_OK;
+}
+
+int fu_backward_join(fu_ctx* c, fu_stream stream) {
   FU_REQUIRE(c, "null context");
-  c->side_on = enable != 0;
+  if (c->side && c->side_mode != 0) {
+    FU_HIP_CHECK(hipEventRecord(c->ev_blk, c->side));
+    FU_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, c->ev_blk, 0));
+    c->wg_pending[0] = c->wg_pending[1] = false;
+  }
   return FU_OK;
 }
 

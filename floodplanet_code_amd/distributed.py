@@ -15,8 +15,14 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
+
+# rehearsal knob: drive the block-wise backward (the multi-GPU code path) in a single process
+_FORCE_BLOCKS = os.environ.get("FU_DP_FORCE_BLOCKS") == "1"
+_DIAG_MODE = None      # tools/dp_diag.py: override of the side-stream mode
 
 
 def plan_buckets(block_ranges: Sequence[Tuple[int, int]], cap_bytes: int = 25 << 20,
@@ -86,6 +92,16 @@ class DataParallelTrainer:
         self._reducer: Optional[BucketedReducer] = None
         self._synced = False
 
+    def _side_mode(self) -> int:
+        if _DIAG_MODE is not None:
+            return _DIAG_MODE
+        env = os.environ.get("FU_DP_SIDE_MODE")
+        if env is not None:
+            return int(env)
+        if self.world_size <= 1:
+            return 2
+        return 2 if dist.get_backend(self.group) == "nccl" else 0
+
     def _sync_initial_state(self, device):
         net = self.net
         if not net._flat_valid:
@@ -102,7 +118,7 @@ class DataParallelTrainer:
             self._sync_initial_state(x.device)
         net._forward_raw(x, True, want_logits=False)
         loss = net._loss_raw(target, ignore_index, x.device)
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not _FORCE_BLOCKS:
             net._backward_raw(None, x.device)
         else:
             if self._reducer is None:
@@ -110,9 +126,19 @@ class DataParallelTrainer:
             lib = _lib.load()
             stream = net._stream(x.device)
             flat = net.flat_grads()
-            for b in range(lib.fu_num_blocks(net._ctx)):
+            # weight gradients run on the context's side stream: join it only where a bucket ends (mode 2), not after
+            # every block, so that the two chains stay concurrent inside a bucket.  Only with RCCL, whose collectives
+            # are kernels on a stream of their own: gloo's worker thread synchronises streams from the host, and next
+            # to the two-stream backward that was measured 30-80x slower (tools/dp_diag.py), so any
+            # other backend gets the serial chain (mode 0).
+            _lib.check(lib.fu_set_side_stream(net._ctx, self._side_mode()))
+            nb = lib.fu_num_blocks(net._ctx)
+            for b in range(nb):
                 _lib.check(lib.fu_backward_block(net._ctx, b, None, stream))
+                if b in self._reducer._by_last or b == nb - 1:
+                    _lib.check(lib.fu_backward_join(net._ctx, stream))
                 self._reducer.block_done(flat, b)
+            _lib.check(lib.fu_set_side_stream(net._ctx, 1))
             self._reducer.finish()
         self.step_count += 1
         net.adam_step(self.lr, self.step_count, self.betas, self.eps,

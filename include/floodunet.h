@@ -129,9 +129,12 @@ int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
 /* The weight-gradient chain of every conv (wgrad, slab reduce, transpose) runs on a context-owned side stream,
  * concurrently with the data-gradient / BatchNorm-backward chain on the caller's stream; fu_backward joins the two
  * before it returns its work to the caller's stream order, fu_backward_block at the end of every block (the block's
- * gradients are then final for a bucketed all-reduce).  enable = 0 keeps everything on the caller's stream (the
- * default when the environment variable FU_NO_SIDE_STREAM is set at fu_create, for bilinear = 0 and in fp32 mode). */
-int fu_set_side_stream(fu_ctx* ctx, int enable);
+ * gradients are then final for a bucketed all-reduce).  mode 0 keeps everything on the caller's stream (the default
+ * when the environment variable FU_NO_SIDE_STREAM is set at fu_create, for bilinear = 0 and in fp32 mode); mode 1
+ * (default) as described; mode 2: fu_backward_block does not join -- the caller calls fu_backward_join(stream) before
+ * it consumes gradients on `stream` (e.g. once per all-reduce bucket instead of once per block). */
+int fu_set_side_stream(fu_ctx* ctx, int mode);
+int fu_backward_join(fu_ctx* ctx, fu_stream stream);
 
 /* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
  * 9 = inc.  After block k returns, the gradient range fu_block_param_range(k) is final on `stream`. */
