@@ -554,7 +554,7 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
   const int pt0 = split * P.perSplit;
   const int pt1 = min(P.nPix, pt0 + P.perSplit);
 #ifdef FU_CONV_STAMPS
-  unsigned long long tStage = 0, tIssue = 0, tMfma = 0, tA = __builtin_amdgcn_s_memtime(), tStart = tA;
+  unsigned long long tStage = 0, tIssue = 0, tMfma = 0, tW = 0, tS = 0, tA = __builtin_amdgcn_s_memtime(), tStart = tA;
 #endif
   if (pt0 < pt1) load_tile(pt0);
   for (int pt = pt0; pt < pt1; ++pt) {
@@ -562,10 +562,19 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
     tA = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();            // previous stage's fragment reads are done (sAB visible on the first pass)
+#ifdef FU_CONV_STAMPS
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
     store_tile();
+#ifdef FU_CONV_STAMPS
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 #ifdef FU_CONV_STAMPS
     const unsigned long long tB = __builtin_amdgcn_s_memtime();
+    if (pt > pt0) { tW += t1 - tA; tS += t3 - t2; }
 #endif
     // in flight under the MFMA block.  ALWAYS issued (the last stage re-reads its own tile): under `if (pt + 1 < pt1)`
     // the staging registers are phis of a loaded and a not-loaded path, hipcc copies some of them right behind the
@@ -621,13 +630,267 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
     }
   }
 #ifdef FU_CONV_STAMPS
-  if (P.dbg && tid == 0) {
+  if (P.dbg && lane == 0 && blockIdx.x < 256) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long* d = P.dbg + (size_t)blockIdx.x * 8;
+    unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
     d[0] = tStage; d[1] = tIssue; d[2] = tMfma; d[3] = (unsigned long long)max(pt1 - pt0 - 1, 0);
-    d[4] = __builtin_amdgcn_s_memtime() - tE; d[5] = __builtin_amdgcn_s_memtime() - tStart;
+    d[4] = __builtin_amdgcn_s_memtime() - tE; d[5] = __builtin_amdgcn_s_memtime() - tStart; d[6] = tW; d[7] = tS;
   }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// wgrad, ping-pong version for c_in tiles of 128 (8 waves, one workgroup per CU)
+//
+// k_wgrad_bf16<4,8> spends half of every stage with the MFMA pipe idle (tools/stamp_wgrad.py: per stage 4450 cycles of
+// MFMA work for the two waves of a SIMD, 2400 BN/ReLU + LDS store, 1900 load issue at the texture unit's 64 B/clk, all
+// in lock step because the single LDS stage needs two barriers).  Here the stage is double-buffered (rows unpadded and
+// XOR-swizzled by 64-byte chunk instead, 2 x 62.5 KB) and the 8 waves form two groups half a stage apart: while waves
+// 0-3 multiply stage n (one wave per SIMD feeds the MFMA pipe alone), waves 4-7 activate and store their half of the
+// next stage and issue the loads after that, then the roles swap.  Every wave runs the same instruction stream
+// { MFMA(n) ; barrier ; store(n+1+grp), load(n+2+grp) ; barrier }; group 1 is shifted by one pre-loop staging step and
+// group 0 pays the matching barrier after the loop.  Accumulators, split-K slabs and the reduce are unchanged, so the
+// results are bit-identical to k_wgrad_bf16<4,8>.
+// ------------------------------------------------------------------------------------------------
+struct WPCfg {
+  static constexpr int CI_T = 128, CO_T = 64, NT = 512, PTH = 8, PTW = 16, GT = 256;
+  static constexpr int HWd = PTW + 2, NHP = (PTH + 2) * HWd, NPX = PTH * PTW;
+  static constexpr int RSX = CI_T, RSD = CO_T;               // unpadded rows (elements)
+  static constexpr int XQ = CI_T / 8, DQ = CO_T / 8;
+  static constexpr int XH_UNITS = NHP * XQ / 2, DH_UNITS = NPX * DQ / 2;   // per group
+  static constexpr int X_ITERS = (XH_UNITS + GT - 1) / GT, D_ITERS = (DH_UNITS + GT - 1) / GT;
+  static constexpr int BUF_ELEMS = NHP * RSX + NPX * RSD;
+  static constexpr int SMEM_BYTES = 2 * BUF_ELEMS * 2 + 2 * CI_T * 4;
+  static_assert((NHP * XQ) % 2 == 0 && XH_UNITS % XQ == 0 && DH_UNITS % DQ == 0, "halves split on row boundaries");
+};
+
+__global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
+  using Cfg = WPCfg;
+  constexpr int CI_T = Cfg::CI_T, CO_T = Cfg::CO_T, GT = Cfg::GT, HWd = Cfg::HWd, NHP = Cfg::NHP;
+  constexpr int PTH = Cfg::PTH, RSX = Cfg::RSX, RSD = Cfg::RSD, XQ = Cfg::XQ, DQ = Cfg::DQ;
+  constexpr int X_ITERS = Cfg::X_ITERS, D_ITERS = Cfg::D_ITERS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sBuf = reinterpret_cast<bf16_t*>(smem_raw);                       // 2 x { X [NHP][RSX], D [NPX][RSD] }
+  float* sAB = reinterpret_cast<float*>(sBuf + 2 * Cfg::BUF_ELEMS);         // [2][CI_T]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int grp = wave >> 2, tg = tid & (GT - 1);
+  const int mi = wave & 3;                 // c_in block of this wave; both c_out blocks: see ni below
+  // waves 0-3 and 4-7 must split the MFMA work so that each group covers all (mi, ni): wave = 4*grp + w, w = 0..3
+  // -> group g owns c_out block ni = g, all four c_in blocks
+  const int ni = grp;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nT = P.nCi * P.nCo;
+  const int split = logical / nT;
+  const int t = logical - split * nT;
+  const int ciT = t / P.nCo, coT = t - ciT * P.nCo;
+  const int ci0 = ciT * CI_T, co0 = coT * CO_T;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  const int g = lane >> 4, gi = lane & 15, tq = gi >> 2, tp = gi & 3;
+  const int tr_ch = 16 * (g & 1) + 4 * tp;
+  const int tr_px = 8 * lh + tq;
+  // swizzled fragment offsets (elements).  X: 64-byte chunk mi of row r sits at chunk mi ^ (r & 3); the rows of a
+  // fragment are c + tr_px (+4) with c a compile-time constant, so four lane offsets cover c & 3 = 0..3.
+  int aoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = tr_px * RSX + ((mi ^ ((j + tr_px) & 3)) * 32) + tr_ch;
+  // D: 128-byte rows, chunk ni of row r at chunk ni ^ ((r >> 1) & 1); rows are 16 r + tr_px (+4)
+  const int boff = tr_px * RSD + ((ni ^ ((tr_px >> 1) & 1)) * 32) + tr_ch;
+
+  const bool has_bn = P.a0 != nullptr;
+  if (has_bn) {
+    for (int c = tid; c < CI_T; c += Cfg::NT) {
+      const int cc = ci0 + c;
+      const bool ok = cc < P.C0;
+      sAB[c] = ok ? P.a0[cc] : 1.f;
+      sAB[CI_T + c] = ok ? P.b0[cc] : 0.f;
+    }
+  }
+  const int xq = tid & (XQ - 1), dq = tid & (DQ - 1);
+  const int cX = ci0 + 8 * xq;
+  const int cD = co0 + 8 * dq;
+  const bool xval = cX < P.Cin, dval = cD < P.Cout;
+  const bool from0 = cX < P.C0;
+  const bool xbn = has_bn && from0 && xval;
+  const bf16_t* xbase = (from0 || !xval) ? P.src0 : P.src1;
+  const int xcs = (from0 || !xval) ? P.C0 : P.C1;
+  const int xcc = !xval ? 0 : (from0 ? cX : cX - P.C0);
+  const int dcc = dval ? cD : 0;
+
+  uint4 rx[X_ITERS], rd[D_ITERS];
+  unsigned xmask = 0, dmask = 0;
+
+  auto load_half = [&](int pt) {
+    const int tx = pt % P.tilesX;
+    const int t2 = pt / P.tilesX;
+    const int bb = t2 / P.tilesY;
+    const int y0 = (t2 % P.tilesY) * PTH;
+    const int x0 = tx * Cfg::PTW;
+    xmask = 0; dmask = 0;
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int ul = tg + it * GT;
+      const int hp = (grp * Cfg::XH_UNITS + ul) / XQ;
+      const int hy = hp / HWd, hx = hp - hy * HWd;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const unsigned ok = unsigned(ul < Cfg::XH_UNITS) & unsigned((unsigned)iy < (unsigned)P.H) &
+                          unsigned((unsigned)ix < (unsigned)P.W);   // bitwise: no exec-mask branches
+      xmask |= ok << it;
+      const int pix = ok ? ((bb * P.H + iy) * P.W + ix) : 0;
+      rx[it] = *reinterpret_cast<const uint4*>(xbase + (int64_t)pix * xcs + xcc);
+    });
+    static_for<0, D_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int ul = tg + it * GT;
+      const int p = (grp * Cfg::DH_UNITS + ul) / DQ;
+      const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+      const unsigned ok = unsigned(ul < Cfg::DH_UNITS) & unsigned(oy < P.H) & unsigned(ox < P.W);
+      dmask |= ok << it;
+      const int pix = ok ? ((bb * P.H + oy) * P.W + ox) : 0;
+      rd[it] = *reinterpret_cast<const uint4*>(P.dy + (int64_t)pix * P.Cout + dcc);
+    });
+  };
+  auto store_half = [&](bf16_t* sX) {
+    bf16_t* sD = sX + NHP * RSX;
+    float4 av0, av1, bv0, bv1;
+    if (xbn) {
+      av0 = *reinterpret_cast<const float4*>(sAB + 8 * xq);
+      av1 = *reinterpret_cast<const float4*>(sAB + 8 * xq + 4);
+      bv0 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq);
+      bv1 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq + 4);
+    }
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int ul = tg + it * GT;
+      if (ul < Cfg::XH_UNITS) {
+        uint4 v = rx[it];
+        // (the packed form of the fast conv kernel -- v_pk_fma_f32 / v_pk_max_i16 -- is 90 instructions shorter per
+        // stage here and was measured 10 % SLOWER, same box: 8.30 -> 9.15 ms per 98 launches)
+        if (xbn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
+        const bool keep = xval && ((xmask >> it) & 1u);
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        const int hp = (grp * Cfg::XH_UNITS + ul) / XQ;
+        *reinterpret_cast<uint4*>(sX + hp * RSX + 8 * (xq ^ ((hp & 3) << 2))) = v;
+      }
+    });
+    static_for<0, D_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int ul = tg + it * GT;
+      if (ul < Cfg::DH_UNITS) {
+        uint4 v = rd[it];
+        const bool keep = dval && ((dmask >> it) & 1u);
+        v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+        const int p = (grp * Cfg::DH_UNITS + ul) / DQ;
+        *reinterpret_cast<uint4*>(sD + p * RSD + 8 * (dq ^ (((p >> 1) & 1) << 2))) = v;
+      }
+    });
+  };
+  auto mfma_stage = [&](const bf16_t* sX) {
+    const bf16_t* sD = sX + NHP * RSX;
+    bf16x8 Af[2], Bf[4];
+    auto loadA = [&](auto Sc) {
+      constexpr int st = decltype(Sc)::value, hr = st / 3, dx = st % 3, c = hr * HWd + dx;
+      const bf16_t* ad = sX + c * RSX + aoff[c & 3];
+      Af[st & 1] = tr_frag(ad, ad + 4 * RSX);
+    };
+    auto loadB = [&](auto Rc) {
+      constexpr int r = decltype(Rc)::value;
+      const bf16_t* bd = sD + r * 16 * RSD + boff;
+      Bf[r & 3] = tr_frag(bd, bd + 4 * RSD);
+    };
+    loadB(std::integral_constant<int, 0>{});
+    loadA(std::integral_constant<int, 0>{});
+    static_for<0, 3 * (PTH + 2)>([&](auto S) {
+      constexpr int st = decltype(S)::value, hr = st / 3, dx = st % 3;
+      if constexpr (st + 1 < 3 * (PTH + 2)) loadA(std::integral_constant<int, st + 1>{});
+      if constexpr (dx == 0 && hr + 1 < PTH) loadB(std::integral_constant<int, hr + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 3>([&](auto DY) {
+        constexpr int dy = decltype(DY)::value, r = hr - dy;
+        if constexpr (r >= 0 && r < PTH)
+          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+      });
+    });
+  };
+
+  const int pt0 = split * P.perSplit;
+  const int pt1 = min(P.nPix, pt0 + P.perSplit);
+  const int T = pt1 - pt0;
+  if (T <= 0) return;       // uniform over the workgroup (cannot happen with the launcher's split)
+  bf16_t* buf0 = sBuf;
+  bf16_t* buf1 = sBuf + Cfg::BUF_ELEMS;
+  __syncthreads();                               // sAB
+  load_half(pt0);
+  store_half(buf0);
+  load_half(min(pt0 + 1, pt1 - 1));
+  __syncthreads();                               // stage 0 complete
+  if (grp) {                                     // group 1 runs half a stage ahead with its staging
+    store_half(buf1);
+    load_half(min(pt0 + 2, pt1 - 1));
+    __syncthreads();
+  }
+#ifdef FU_CONV_STAMPS
+  unsigned long long tM = 0, tB1 = 0, tSt = 0, tLd = 0, tB2 = 0, tStart = __builtin_amdgcn_s_memtime();
+#endif
+  for (int n = 0; n < T; ++n) {
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+    mfma_stage((n & 1) ? buf1 : buf0);
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long s2b = __builtin_amdgcn_s_memtime();
+#endif
+    // stage n+1+grp (already in registers) -> the other buffer of that stage's parity; past the last stage this stores a
+    // copy of the last tile into a buffer nobody reads any more (unconditional on purpose: conditional loads become
+    // phis that hipcc waits for in front of the MFMA block)
+    store_half(((n + 1 + grp) & 1) ? buf1 : buf0);
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+#endif
+    load_half(min(pt0 + n + 2 + grp, pt1 - 1));
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s5 = __builtin_amdgcn_s_memtime();
+    if (n > 0) { tM += s1 - s0; tB1 += s2 - s1; tSt += s3 - s2b; tLd += s4 - s3; tB2 += s5 - s4; tStart += 0; }
+    if (n == 0) tStart = s2b - s2;   // (load wait sample)
+#endif
+  }
+  if (!grp) __syncthreads();                     // group 1's pre-loop barrier
+#ifdef FU_CONV_STAMPS
+  if (P.dbg && lane == 0 && blockIdx.x < 256) {
+    unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    d[0] = tM; d[1] = tB1; d[2] = tSt; d[3] = (unsigned long long)max(T - 1, 0); d[4] = tLd; d[5] = tB2; d[6] = tStart; d[7] = 0;
+  }
+#endif
+
+  const int co = co0 + ni * 32 + l31;
+  if (co < P.Cout) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[tap][r];
+      }
+    }
+  }
 }
 
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
@@ -660,6 +923,37 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
   return 0;
 }
 
+#ifndef FU_WGRAD_LOCKSTEP_DEFAULT
+#define FU_WGRAD_LOCKSTEP_DEFAULT 0   // A/B builds: -DFU_WGRAD_LOCKSTEP_DEFAULT=1
+#endif
+int g_wgrad_force_lockstep = FU_WGRAD_LOCKSTEP_DEFAULT;   // testing hook (fu_test_force_lockstep_wgrad): k_wgrad_bf16<4,8> instead of the ping-pong kernel
+
+static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
+  using Cfg = WPCfg;
+  P.tilesX = ceil_div(P.W, Cfg::PTW); P.tilesY = ceil_div(P.H, Cfg::PTH);
+  P.nPix = P.B * P.tilesX * P.tilesY;
+  P.nCi = ceil_div(P.Cin, Cfg::CI_T); P.nCo = ceil_div(P.Cout, Cfg::CO_T);
+  const int nT = P.nCi * P.nCo;
+  int S = ceil_div(target_wgs, nT);
+  if (S > P.nPix) S = P.nPix;
+  if (S < 1) S = 1;
+  P.perSplit = ceil_div(P.nPix, S);
+  P.S = ceil_div(P.nPix, P.perSplit);     // every split owns at least one stage
+  static bool attr_set = false;
+  if (!attr_set) {
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16_pp),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    attr_set = true;
+  }
+  const ProfSlot ps = g_prof_slot;
+  g_prof_slot = ProfSlot();
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL(k_wgrad_bf16_pp, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
 // upper bound of the slab size over the two configurations below
 int64_t conv3x3_wgrad_slab_elems_bf16(int Cin, int Cout, int B, int H, int W) {
   const int64_t npix = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
@@ -682,7 +976,8 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   P.dbg = g_conv_dbg;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0 && Cout % 8 == 0, "wgrad_bf16: channel counts must be multiples of 8");
   int st;
-  if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  if (P.Cin > 64 && !g_wgrad_force_lockstep) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);
   else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;
   return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
@@ -691,4 +986,5 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
 }  // namespace fu
 
 extern "C" void fu_test_force_general_conv(int on) { fu::g_bf16_force_general = on; }
+extern "C" void fu_test_force_lockstep_wgrad(int on) { fu::g_wgrad_force_lockstep = on; }
 extern "C" void fu_debug_set_conv_stamps(void* p) { fu::g_conv_dbg = (unsigned long long*)p; }

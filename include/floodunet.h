@@ -201,6 +201,9 @@ int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* to
 /* Testing hook: on != 0 makes every bf16 3x3 convolution (forward / dgrad) run on the general kernel even when the
  * shape is eligible for the aligned-shape fast kernel, so that the parity tests can cover both.  Process-wide. */
 void fu_test_force_general_conv(int on);
+/* Testing hook: on != 0 runs the bf16 weight gradient of c_in > 64 on the lock-step kernel k_wgrad_bf16<4,8> instead of
+ * the ping-pong kernel k_wgrad_bf16_pp (same accumulation order: the results are bit-identical).  Process-wide. */
+void fu_test_force_lockstep_wgrad(int on);
 
 /* ---- single operators (per-op parity tests; NHWC device buffers of the context's precision) -- */
 /* element size of the activation type for `precision` */

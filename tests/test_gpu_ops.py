@@ -242,8 +242,43 @@ def test_conv3x3_bf16_dgrad(shape, conv_path):
     assert rel_err(got, ref) < 4e-3
 
 
+@pytest.fixture(params=["auto", "lockstep"])
+def wgrad_path(request):
+    """bf16 wgrad of c_in > 64 has a ping-pong kernel and a lock-step one: run every shape on both."""
+    lib = _lib.load()
+    lib.fu_test_force_lockstep_wgrad(1 if request.param == "lockstep" else 0)
+    yield request.param
+    lib.fu_test_force_lockstep_wgrad(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 64, 40, 24, True), (1, 96, 0, 32, 16, 16, False),
+                                   (16, 128, 0, 128, 32, 32, True), (3, 256, 0, 72, 19, 50, True),
+                                   (1, 128, 128, 64, 8, 16, True)])
+def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape):
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=5)
+    g = torch.Generator().manual_seed(6)
+    ddy = nhwc_bf(torch.randn(B, Cout, H, W, generator=g))
+    d0, d1 = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None)
+    da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
+    outs = []
+    for lock in (0, 1):
+        lib.fu_test_force_lockstep_wgrad(lock)
+        dw = torch.full(w.shape, float("nan"), device=DEV)
+        try:
+            check(lib.fu_op_conv3x3_wgrad(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw),
+                                          B, H, W, stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.fu_test_force_lockstep_wgrad(0)
+        outs.append(dw.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_wgrad(shape):
+def test_conv3x3_bf16_wgrad(shape, wgrad_path):
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=2)

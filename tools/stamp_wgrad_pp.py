@@ -1,4 +1,4 @@
-"""Per-phase s_memtime breakdown of k_wgrad_bf16 (library built with `make EXTRA=-DFU_CONV_STAMPS`)."""
+"""Per-wave, per-phase s_memtime breakdown of k_wgrad_bf16_pp (library built with `make EXTRA=-DFU_CONV_STAMPS`)."""
 import sys, ctypes as C, torch, numpy as np
 sys.path.insert(0, '.')
 from floodplanet_code_amd import _lib
@@ -15,13 +15,11 @@ def run(B, C0, Cout, H, W):
         raw.fu_debug_set_conv_stamps(dbg.data_ptr() if it == 2 else None)
         check(lib.fu_op_conv3x3_wgrad(1, ptr(x), C0, ptr(a), ptr(b), None, 0, ptr(dy), Cout, ptr(dw), B, H, W, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize(); raw.fu_debug_set_conv_stamps(None)
-    dall = dbg.view(256, 8, 8).cpu().numpy().astype(np.float64)
+    d = dbg.view(256, 8, 8).cpu().numpy().astype(np.float64)
+    print(f"{C0}->{Cout}@{H}")
     for w in range(8):
-        dw_ = dall[:, w]; dw_ = dw_[dw_[:, 3] > 0]
-        if len(dw_): n_ = dw_[:, 3]; print(f'   wave {w}: stage {np.median(dw_[:,0]/n_):.0f} (barrier1 {np.median(dw_[:,6]/n_):.0f}, bn+store {np.median(dw_[:,7]/n_):.0f}) issue {np.median(dw_[:,1]/n_):.0f} mfma {np.median(dw_[:,2]/n_):.0f}')
-    d = dall[:, 0]
-    d = d[d[:, 3] > 0]; n = d[:, 3]
-    print(f"{C0}->{Cout}@{H}: wgs {len(d)} stages/wg {np.median(n)+1:.0f} | per stage: wait+stage+barriers {np.median(d[:,0]/n):.0f} (barrier1 {np.median(d[:,6]/n):.0f}, bn+store {np.median(d[:,7]/n):.0f}) | load issue {np.median(d[:,1]/n):.0f} | mfma {np.median(d[:,2]/n):.0f} || epilogue+drain {np.median(d[:,4]):.0f} | lifetime {np.median(d[:,5]):.0f}")
-run(16, 64, 64, 256, 256)
+        v = d[:, w]; v = v[v[:, 3] > 0]; n = v[:, 3]
+        m = lambda k: np.median(v[:, k] / n)
+        print(f"   wave {w}: mfma {m(0):.0f} | barrier1 {m(1):.0f} | bn+store {m(2):.0f} | load issue {m(4):.0f} | barrier2 {m(5):.0f} | sum {m(0)+m(1)+m(2)+m(4)+m(5):.0f}   (first load wait {np.median(v[:,6]):.0f})")
 run(16, 128, 128, 128, 128)
 run(16, 512, 512, 32, 32)
