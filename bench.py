@@ -132,6 +132,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if world > 1:   # communicator set-up + parameter broadcast outside the steps (also with --warmup 0)
+        trainer._sync_initial_state(dev)
     for _ in range(args.warmup):
         trainer.step(x, target, 0)
     lib = _lib.load()

@@ -16,13 +16,18 @@ tf=tw=td=0
 for i,r in enumerate(fw[:18]):
     cin,cout,hw=convs[i]; fl=2*9*cin*cout*hw*hw*B; d=dur(r); tf+=d
     print(f"fwd  {i:2d} {cin:5d}->{cout:4d} @{hw:3d} {r['Kernel_Name'][14:36]:22s} {d:7.1f} us {fl/d/1e6:7.1f} TF  wgs={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}")
-k=18
+# backward: the weight-gradient chain runs on a side stream, so start-time order interleaves the two kernels of a conv
+# arbitrarily; classify by kernel name (each stream keeps its own launch order: conv 17 first)
+bw_w=[r for r in fw[18:] if 'k_wgrad' in r['Kernel_Name']]
+bw_d=[r for r in fw[18:] if 'k_wgrad' not in r['Kernel_Name']]
+assert len(bw_w)==18 and len(bw_d)==17, (len(bw_w), len(bw_d))
+kw=kd=0
 for i in reversed(range(18)):
     cin,cout,hw=convs[i]; fl=2*9*cin*cout*hw*hw*B
-    r=fw[k]; k+=1; d=dur(r); tw+=d
-    s=f"bwd  {i:2d} {cin:5d}->{cout:4d} @{hw:3d} wgrad {d:7.1f} us {fl/d/1e6:7.1f} TF wgs={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}"
+    r=bw_w[kw]; kw+=1; d=dur(r); tw+=d
+    s=f"bwd  {i:2d} {cin:5d}->{cout:4d} @{hw:3d} wgrad {r['Kernel_Name'][:40].split('(')[0][-20:]:20s} {d:7.1f} us {fl/d/1e6:7.1f} TF wgs={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}"
     if i!=0:
-        r=fw[k]; k+=1; d=dur(r); td+=d
+        r=bw_d[kd]; kd+=1; d=dur(r); td+=d
         s+=f" | dgrad {r['Kernel_Name'][14:36]:22s} {d:7.1f} us {fl/d/1e6:7.1f} TF wgs={int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}"
     print(s)
 print("fwd us",tf,"wgrad us",tw,"dgrad us",td)

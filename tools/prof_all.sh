@@ -9,6 +9,9 @@ tail -c 1600 gpurun_out/bench_bf16.json
 python3 bench.py --steps 10 --warmup 3 --dtype f32 --no-cpu-baseline > gpurun_out/bench_f32.json 2> gpurun_out/bench_f32.err
 tail -c 700 gpurun_out/bench_f32.json
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1b_bf16 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-serial-pass > gpurun_out/r1b_bf16.log 2>&1
+export FU_NO_SIDE_STREAM=1   # one stream: per-kernel durations without the two backward chains sharing the GPU
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1b_bf16_serial -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-serial-pass > gpurun_out/r1b_bf16_serial.log 2>&1
+unset FU_NO_SIDE_STREAM
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1b_f32 -- python3 bench.py --steps 5 --warmup 2 --dtype f32 --no-cpu-baseline --no-serial-pass > gpurun_out/r1b_f32.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass > gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass > gpurun_out/pmc_write.log 2>&1
