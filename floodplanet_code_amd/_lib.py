@@ -29,6 +29,8 @@ class FuConfig(C.Structure):
         ("width", C.c_int32),
         ("precision", C.c_int32),
         ("device", C.c_int32),
+        ("n_encoders", C.c_int32),
+        ("enc_channels", C.c_int32 * 6),
     ]
 
 

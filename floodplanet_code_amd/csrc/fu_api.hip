@@ -187,7 +187,9 @@ enum BlockKind { BK_INC = 0, BK_DOWN = 1, BK_UP = 2 };
 struct Block {
   Conv c[2];
   int kind = BK_INC, level = 0;
-  int skip = -1;              // BK_UP: encoder block whose output is concatenated first
+  int enc = 0;                // BK_INC / BK_DOWN: encoder this block belongs to
+  int role = 0;               // 0..8 = inc, down1..4, up1..4 (names, flops)
+  int skip = -1;              // BK_UP: level whose feature is concatenated first
   void* pooled = nullptr;     // BK_DOWN: maxpool output (input of c[0])
   void* g_pooled = nullptr;
   void* up = nullptr;         // BK_UP: upsampled + padded low-resolution input
@@ -203,6 +205,22 @@ struct Block {
   void* ct_wd = nullptr;
   int first_param = 0, num_params = 0;  // contiguous range in the canonical parameter table
 };
+
+// Late fusion, one per level (lf_model.py:40-45, 78-90): fused = Conv2d(nE*C, C, 1)(cat_e relu(bn(x_e)))
+struct Fuse {
+  int p_w = -1, p_b = -1, C = 0;
+  void* cat = nullptr;        // [pixels][nE*C]: activated encoder features side by side
+  void* gcat = nullptr;       // its gradient
+  void* y = nullptr;          // fused feature (plain: no BN / ReLU follows)
+  void* gy = nullptr;         // its gradient (written by the decoder's backward)
+  float* w3 = nullptr;        // the 1x1 weight as the centre tap of a 3x3 one, OIHW fp32
+  float* dw3 = nullptr;
+  void* wf = nullptr;         // packed forward / dgrad copies
+  void* wd = nullptr;
+};
+
+// what the decoder reads at one level: the encoder's own conv output (plain UNet) or the fused feature
+struct Feat { void* y; float* a; float* b; void* gy; int C; };
 
 struct ProfRec { int cls; double flops; hipEvent_t e0, e1; };
 struct Profiler {
@@ -243,11 +261,16 @@ struct fu_ctx {
   Prec prec;
   size_t esize;
   int Hs[5], Ws[5], ch[5];
-  int cin_pad0;
+  int nE = 1;                  // encoders (1 for the plain UNet)
+  bool fusion = false;         // late fusion: nE encoders -> 5 fusion convs -> decoder
+  int nb = 9;                  // blocks: 5 per encoder (inc, down1..4), then up1..4
+  int enc_ch[FU_MAX_ENCODERS] = {0}, enc_coff[FU_MAX_ENCODERS] = {0}, cin_pad0[FU_MAX_ENCODERS] = {0};
+  void* xin[FU_MAX_ENCODERS] = {nullptr};
   std::vector<ParamInfo> params;
   std::vector<BnInfo> bns;
   int64_t total_params = 0, total_bn = 0;
-  Block blk[9];
+  std::vector<Block> blk;
+  Fuse fuse[5];
   int p_outw = -1, p_outb = -1;
   // bound (caller-owned)
   float* P = nullptr;
@@ -259,7 +282,6 @@ struct fu_ctx {
   // owned
   Arena arena;
   std::vector<void*> extra_allocs;
-  void* xin = nullptr;
   float* logits = nullptr;
   float* dlogits = nullptr;
   float* stats = nullptr;
@@ -282,7 +304,7 @@ struct fu_ctx {
   float* adam_m = nullptr;
   float* adam_v = nullptr;
   Profiler prof;
-  PackTable pack_tab;
+  std::vector<PackTable> pack_tabs;   // <= MAX_PACK layers per launch
   // state
   int last_batch = 0;
   bool fwd_training = false;
@@ -291,7 +313,7 @@ struct fu_ctx {
 
 namespace {
 
-std::string dc_prefix(int i) {
+std::string dc_prefix(int i) {   // i = block role
   if (i == 0) return "inc.double_conv";
   if (i <= 4) return "down" + std::to_string(i) + ".maxpool_conv.1.double_conv";
   return "up" + std::to_string(i - 4) + ".conv.double_conv";
@@ -375,34 +397,57 @@ int build_plan(fu_ctx* c) {
   c->Hs[0] = f.height; c->Ws[0] = f.width;
   for (int l = 1; l < 5; ++l) { c->Hs[l] = c->Hs[l - 1] / 2; c->Ws[l] = c->Ws[l - 1] / 2; }
   FU_REQUIRE(c->Hs[4] >= 1 && c->Ws[4] >= 1, "tile %dx%d is too small for four 2x poolings", f.height, f.width);
-  c->cin_pad0 = round_up(f.n_channels, c->prec == PREC_F32 ? 4 : 8);
+  c->fusion = f.n_encoders >= 1;
+  c->nE = c->fusion ? f.n_encoders : 1;
+  c->nb = 5 * c->nE + 4;
+  c->blk.assign(c->nb, Block());
+  for (int e = 0, off = 0; e < c->nE; ++e) {
+    c->enc_ch[e] = c->fusion ? f.enc_channels[e] : f.n_channels;
+    c->enc_coff[e] = off;
+    off += c->enc_ch[e];
+    c->cin_pad0[e] = round_up(c->enc_ch[e], c->prec == PREC_F32 ? 4 : 8);
+  }
   const int outs[4] = {base * 8 / factor, base * 4 / factor, base * 2 / factor, base};
 
   int low = c->ch[4];
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < c->nb; ++i) {
     Block& K = c->blk[i];
     int cin, cmid, cout;
-    if (i == 0) { K.kind = BK_INC; K.level = 0; cin = f.n_channels; cmid = cout = c->ch[0]; }
-    else if (i <= 4) { K.kind = BK_DOWN; K.level = i; cin = c->ch[i - 1]; cmid = cout = c->ch[i]; }
+    const bool is_enc = i < 5 * c->nE;
+    K.enc = is_enc ? i / 5 : 0;
+    K.role = is_enc ? i % 5 : 5 + (i - 5 * c->nE);
+    const int r = K.role;
+    if (r == 0) { K.kind = BK_INC; K.level = 0; cin = c->enc_ch[K.enc]; cmid = cout = c->ch[0]; }
+    else if (r <= 4) { K.kind = BK_DOWN; K.level = r; cin = c->ch[r - 1]; cmid = cout = c->ch[r]; }
     else {
-      const int k = i - 5;
+      const int k = r - 5;
       K.kind = BK_UP; K.skip = 3 - k; K.level = 3 - k;
       if (f.bilinear) { cin = low + c->ch[3 - k]; cmid = cin / 2; cout = outs[k]; }
       else { K.ct_cin = low; K.ct_cout = low / 2; cin = low / 2 + c->ch[3 - k]; cmid = cout = outs[k]; }
       low = cout;
     }
+    if (c->fusion && r == 5) {   // between the encoders and the decoder in the flat buffers (backward order stays adjacent)
+      for (int l = 0; l < 5; ++l) {
+        Fuse& F = c->fuse[l];
+        F.C = c->ch[l];
+        const std::string cn = "concat_convs." + std::to_string(l);
+        F.p_w = add_param(c, cn + ".weight", {F.C, (int64_t)c->nE * F.C, 1, 1});
+        F.p_b = add_param(c, cn + ".bias", {F.C});
+      }
+    }
+    const std::string scope = !c->fusion ? "" : (is_enc ? "encoders." + std::to_string(K.enc) + "." : "decoder.");
     K.first_param = (int)c->params.size();
     if (K.kind == BK_UP && !f.bilinear) {
-      const std::string up = "up" + std::to_string(i - 4) + ".up";
+      const std::string up = scope + "up" + std::to_string(r - 4) + ".up";
       K.ct_w = add_param(c, up + ".weight", {K.ct_cin, K.ct_cout, 2, 2});
       K.ct_b = add_param(c, up + ".bias", {K.ct_cout});
     }
-    const std::string pre = dc_prefix(i);
+    const std::string pre = scope + dc_prefix(r);
     for (int j = 0; j < 2; ++j) {
       Conv& v = K.c[j];
       v.level = K.level;
       v.cin_real = j == 0 ? cin : cmid;
-      v.cin_pad = (i == 0 && j == 0) ? c->cin_pad0 : v.cin_real;
+      v.cin_pad = (r == 0 && j == 0) ? c->cin_pad0[K.enc] : v.cin_real;
       v.cout = j == 0 ? cmid : cout;
       const std::string cn = pre + "." + std::to_string(j == 0 ? 0 : 3);
       const std::string bn = pre + "." + std::to_string(j == 0 ? 1 : 4);
@@ -416,8 +461,9 @@ int build_plan(fu_ctx* c) {
     }
     K.num_params = (int)c->params.size() - K.first_param;
   }
-  c->p_outw = add_param(c, "outc.conv.weight", {f.n_classes, base, 1, 1});
-  c->p_outb = add_param(c, "outc.conv.bias", {f.n_classes});
+  const std::string dscope = c->fusion ? "decoder." : "";
+  c->p_outw = add_param(c, dscope + "outc.conv.weight", {f.n_classes, base, 1, 1});
+  c->p_outb = add_param(c, dscope + "outc.conv.bias", {f.n_classes});
   return 0;
 }
 
@@ -427,10 +473,10 @@ int alloc_workspace(fu_ctx* c) {
   Arena& A = c->arena;
   const size_t es = c->esize;
   auto act = [&](int level, int C) { return (size_t)B * c->Hs[level] * c->Ws[level] * C * es; };
-  A.want(&c->xin, act(0, c->cin_pad0));
+  for (int e = 0; e < c->nE; ++e) A.want(&c->xin[e], act(0, c->cin_pad0[e]));
   int64_t max_stats = 0, max_bnb = 0, max_slab = 0, max_dbp = 0;
   int max_c = 0;
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < c->nb; ++i) {
     Block& K = c->blk[i];
     for (int j = 0; j < 2; ++j) {
       Conv& v = K.c[j];
@@ -444,7 +490,7 @@ int alloc_workspace(fu_ctx* c) {
       A.want(&v.b, v.cout * sizeof(float));
       A.want(&v.coef, v.cout * 2 * sizeof(float));
       A.want(&v.wf, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
-      if (!(i == 0 && j == 0)) A.want(&v.wd, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
+      if (!(K.role == 0 && j == 0)) A.want(&v.wd, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
       max_stats = std::max<int64_t>(max_stats, (int64_t)conv3x3_num_stat_tiles(c->prec, B, H, W) * v.cout * 2);
       max_bnb = std::max<int64_t>(max_bnb, bn_bwd_partial_elems(v.cout, npix));
       max_dbp = std::max<int64_t>(max_dbp, bn_bwd_partial_elems(v.cout, npix) / 2);
@@ -471,6 +517,20 @@ int alloc_workspace(fu_ctx* c) {
       }
     }
   }
+  for (int l = 0; l < 5 && c->fusion; ++l) {
+    Fuse& F = c->fuse[l];
+    const int Ccat = c->nE * F.C, H = c->Hs[l], W = c->Ws[l];
+    A.want(&F.cat, act(l, Ccat));
+    A.want(&F.gcat, act(l, Ccat));
+    A.want(&F.y, act(l, F.C));
+    A.want(&F.gy, act(l, F.C));
+    A.want(&F.w3, (size_t)9 * Ccat * F.C * sizeof(float));
+    A.want(&F.dw3, (size_t)9 * Ccat * F.C * sizeof(float));
+    A.want(&F.wf, conv3x3_pack_elems(c->prec, Ccat, F.C) * es);
+    A.want(&F.wd, conv3x3_pack_elems(c->prec, Ccat, F.C) * es);
+    max_slab = std::max<int64_t>(max_slab, conv3x3_wgrad_slab_elems(c->prec, Ccat, F.C, B, H, W));
+    max_dbp = std::max<int64_t>(max_dbp, (int64_t)2048 * F.C);
+  }
   const int64_t npix0 = (int64_t)B * f.height * f.width;
   A.want(&c->logits, npix0 * f.n_classes * sizeof(float));
   A.want(&c->dlogits, npix0 * f.n_classes * sizeof(float));
@@ -488,7 +548,7 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->adam_m, c->total_params * sizeof(float));
   A.want(&c->adam_v, c->total_params * sizeof(float));
   FU_TRY(A.commit());
-  for (int i = 5; i < 9 && f.bilinear; ++i) {
+  for (int i = 5 * c->nE; i < c->nb && f.bilinear; ++i) {
     Block& K = c->blk[i];
     const int lowlvl = K.level + 1;
     FU_TRY(build_up_tables(c, c->Hs[lowlvl], c->Ws[lowlvl], &K.upt));
@@ -512,14 +572,24 @@ inline float* P(fu_ctx* c, int idx) { return c->P + c->params[idx].off; }
 inline float* G(fu_ctx* c, int idx) { return c->G + c->params[idx].off; }
 
 int repack(fu_ctx* c, hipStream_t s) {
-  PackTable& t = c->pack_tab;
-  if (t.n == 0) {
-    int64_t start = 0;
+  if (c->pack_tabs.empty()) {
     bool tiled_ok = true;
-    t.tiles = 0;
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < c->nb; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const Conv& v = c->blk[i].c[j];
+        if (v.cout % 8 != 0 || v.cin_pad % 8 != 0) tiled_ok = false;
+      }
+    int64_t start = 0;
+    for (int i = 0; i < c->nb; ++i)
       for (int j = 0; j < 2; ++j) {
         Conv& v = c->blk[i].c[j];
+        if (c->pack_tabs.empty() || c->pack_tabs.back().n == MAX_PACK) {   // one launch per MAX_PACK layers
+          PackTable nt;
+          nt.n = 0; nt.total = 0; nt.tiles = 0;
+          c->pack_tabs.push_back(nt);
+          start = 0;
+        }
+        PackTable& t = c->pack_tabs.back();
         PackDesc& d = t.d[t.n++];
         d.start = start;
         d.w_off = c->params[v.p_w].off;
@@ -529,22 +599,29 @@ int repack(fu_ctx* c, hipStream_t s) {
         d.tile_start = t.tiles;
         d.tiles_ci = fu::ceil_div(v.cin_pad, 32);
         t.tiles += fu::ceil_div(v.cout, 32) * d.tiles_ci;
-        if (v.cout % 8 != 0 || v.cin_pad % 8 != 0) tiled_ok = false;
+        t.total = start;
       }
-    t.total = start;
-    if (!tiled_ok) t.tiles = 0;
+    if (!tiled_ok) for (PackTable& t : c->pack_tabs) t.tiles = 0;
   }
   const int grid = 2048;
-  if (c->prec == PREC_F32)
-    hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t);
-  else if (t.tiles > 0)
-    hipLaunchKernelGGL(k_pack_tiles_bf16, dim3(t.tiles), dim3(256), 0, s, c->P, t);
-  else
-    hipLaunchKernelGGL((k_pack_all<bf16_t, true>), dim3(grid), dim3(256), 0, s, c->P, t);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
+  for (const PackTable& t : c->pack_tabs) {
+    if (c->prec == PREC_F32)
+      hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t);
+    else if (t.tiles > 0)
+      hipLaunchKernelGGL(k_pack_tiles_bf16, dim3(t.tiles), dim3(256), 0, s, c->P, t);
+    else
+      hipLaunchKernelGGL((k_pack_all<bf16_t, true>), dim3(grid), dim3(256), 0, s, c->P, t);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
+  }
+  for (int l = 0; l < 5 && c->fusion; ++l) {
+    Fuse& F = c->fuse[l];
+    const int Ccat = c->nE * F.C;
+    FU_TRY(launch_center_to_w3(P(c, F.p_w), (int64_t)F.C * Ccat, F.w3, s));
+    FU_TRY(launch_pack_conv3x3(c->prec, F.w3, F.C, Ccat, Ccat, F.wf, F.wd, s));
+  }
   if (!c->cfg.bilinear) {
-    for (int i = 5; i < 9; ++i) {
+    for (int i = 5 * c->nE; i < c->nb; ++i) {
       Block& K = c->blk[i];
       FU_TRY(launch_convT_to_w3(P(c, K.ct_w), K.ct_cin, K.ct_cout, K.ct_w3, s));
       FU_TRY(launch_pack_conv3x3(c->prec, K.ct_w3, K.ct_cout, K.ct_cin, K.ct_cin, K.ct_wf, K.ct_wd, s));
@@ -554,6 +631,18 @@ int repack(fu_ctx* c, hipStream_t s) {
   return 0;
 }
 
+// decoder inputs: the feature of `level` (skip connection) and the low-resolution input of up block i
+Feat level_feat(fu_ctx* c, int level) {
+  if (c->fusion) { Fuse& F = c->fuse[level]; return Feat{F.y, nullptr, nullptr, F.gy, F.C}; }
+  Conv& v = c->blk[level].c[1];
+  return Feat{v.y, v.a, v.b, v.gy, v.cout};
+}
+Feat low_feat(fu_ctx* c, int i) {
+  if (i == 5 * c->nE) return level_feat(c, 4);
+  Conv& v = c->blk[i - 1].c[1];
+  return Feat{v.y, v.a, v.b, v.gy, v.cout};
+}
+
 ConvIn conv_input(fu_ctx* c, int i, int j) {
   Block& K = c->blk[i];
   ConvIn in;
@@ -561,13 +650,13 @@ ConvIn conv_input(fu_ctx* c, int i, int j) {
   if (j == 1) {
     in.src0 = K.c[0].y; in.C0 = K.c[0].cout; in.a0 = K.c[0].a; in.b0 = K.c[0].b;
   } else if (K.kind == BK_INC) {
-    in.src0 = c->xin; in.C0 = c->cin_pad0;
+    in.src0 = c->xin[K.enc]; in.C0 = c->cin_pad0[K.enc];
   } else if (K.kind == BK_DOWN) {
     in.src0 = K.pooled; in.C0 = K.c[0].cin_real;
   } else {
-    Conv& sk = c->blk[K.skip].c[1];
-    in.src0 = sk.y; in.C0 = sk.cout; in.a0 = sk.a; in.b0 = sk.b;
-    in.src1 = K.up; in.C1 = K.c[0].cin_real - sk.cout;
+    const Feat sk = level_feat(c, K.skip);
+    in.src0 = sk.y; in.C0 = sk.C; in.a0 = sk.a; in.b0 = sk.b;
+    in.src1 = K.up; in.C1 = K.c[0].cin_real - sk.C;
   }
   return in;
 }
@@ -591,20 +680,63 @@ int conv_fwd(fu_ctx* c, int i, int j, int B, bool training, hipStream_t s) {
   return 0;
 }
 
+// Late fusion, all five levels (lf_model.py:78-90).  forward: cat <- [relu(bn(x_e))]_e ; fused = W * cat + bias.
+int fuse_forward(fu_ctx* c, int B, hipStream_t s) {
+  for (int l = 0; l < 5; ++l) {
+    Fuse& F = c->fuse[l];
+    const int Ccat = c->nE * F.C, H = c->Hs[l], W = c->Ws[l];
+    const int64_t npix = (int64_t)B * H * W;
+    for (int e = 0; e < c->nE; ++e) {
+      Conv& v = c->blk[5 * e + l].c[1];
+      FU_TRY(launch_copy_channels(c->prec, v.y, v.cout, 0, v.a, v.b, F.cat, Ccat, e * F.C, F.C, npix, s));
+    }
+    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3(c->prec, in, F.wf, P(c, F.p_b), F.y, F.C, nullptr, 0, nullptr, nullptr, B, H, W, s));
+  }
+  return 0;
+}
+
+// backward of the five fusion convs: needs every F.gy (complete after up1's backward); writes dL/d(activated feature)
+// of every encoder level ("=": the encoders' pool backward accumulates into it afterwards, as the skip gradient of
+// the plain UNet) and the fusion parameters' gradients
+int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
+  for (int l = 4; l >= 0; --l) {
+    Fuse& F = c->fuse[l];
+    const int Ccat = c->nE * F.C, H = c->Hs[l], W = c->Ws[l];
+    const int64_t npix = (int64_t)B * H * W;
+    int ndbp = 0;
+    FU_TRY(launch_channel_partial_sums(c->prec, F.gy, F.C, npix, c->db_part, &ndbp, s));
+    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3_wgrad(c->prec, in, F.gy, F.C, c->slab, F.dw3, Ccat, c->db_part, ndbp, G(c, F.p_b), B, H, W,
+                                s));
+    FU_TRY(launch_center_from_w3(F.dw3, (int64_t)F.C * Ccat, G(c, F.p_w), s));
+    ConvIn gin{F.gy, F.C, nullptr, nullptr, nullptr, 0};
+    FU_TRY(launch_conv3x3(c->prec, gin, F.wd, nullptr, F.gcat, Ccat, nullptr, 0, nullptr, nullptr, B, H, W, s));
+    for (int e = 0; e < c->nE; ++e) {
+      Conv& v = c->blk[5 * e + l].c[1];
+      FU_TRY(launch_copy_channels(c->prec, F.gcat, Ccat, e * F.C, nullptr, nullptr, v.gy, v.cout, 0, F.C, npix, s));
+    }
+  }
+  return 0;
+}
+
 int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_out, hipStream_t s) {
   const fu_config& f = c->cfg;
   if (c->packed_dirty) FU_TRY(repack(c, s));
-  FU_TRY(launch_nchw_to_nhwc(c->prec, x, c->xin, B, f.n_channels, f.height, f.width, c->cin_pad0, s));
-  for (int i = 0; i < 9; ++i) {
+  for (int e = 0; e < c->nE; ++e)
+    FU_TRY(launch_nchw_to_nhwc(c->prec, x, c->xin[e], B, c->enc_ch[e], f.height, f.width, c->cin_pad0[e], s,
+                               f.n_channels, c->enc_coff[e]));
+  for (int i = 0; i < c->nb; ++i) {
     Block& K = c->blk[i];
+    if (c->fusion && i == 5 * c->nE) FU_TRY(fuse_forward(c, B, s));
     if (K.kind == BK_DOWN) {
       Conv& pv = c->blk[i - 1].c[1];
       FU_TRY(launch_maxpool2(c->prec, pv.y, pv.a, pv.b, K.pooled, B, c->Hs[pv.level], c->Ws[pv.level], pv.cout, s));
     } else if (K.kind == BK_UP) {
-      Conv& pv = c->blk[i - 1].c[1];
-      const int h = c->Hs[pv.level], w = c->Ws[pv.level], H = c->Hs[K.level], W = c->Ws[K.level];
+      const Feat pv = low_feat(c, i);
+      const int h = c->Hs[K.level + 1], w = c->Ws[K.level + 1], H = c->Hs[K.level], W = c->Ws[K.level];
       if (c->cfg.bilinear) {
-        FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, h, w, pv.cout, H, W, K.upt, s));
+        FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, h, w, pv.C, H, W, K.upt, s));
       } else {
         // ConvTranspose2d(k2,s2) (unet.py:48-51) = 3x3 conv of the zero-stuffed input, then F.pad (unet.py:57-62)
         FU_TRY(launch_zero_stuff(c->prec, pv.y, pv.a, pv.b, K.u, B, h, w, K.ct_cin, H, W, s));
@@ -617,7 +749,7 @@ int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_
     FU_TRY(conv_fwd(c, i, 0, B, training, s));
     FU_TRY(conv_fwd(c, i, 1, B, training, s));
   }
-  Conv& last = c->blk[8].c[1];
+  Conv& last = c->blk[c->nb - 1].c[1];
   FU_TRY(launch_head_fwd(c->prec, last.y, last.a, last.b, P(c, c->p_outw), P(c, c->p_outb), f.base_channels,
                          f.n_classes, B, f.height, f.width, c->logits, logits_out, s));
   c->last_batch = B;
@@ -662,7 +794,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     c->wg_parity ^= 1;
   }
   // data gradient
-  if (!(i == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
+  if (!(K.role == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
   if (j == 1) {
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.c[0].gy, K.c[0].cout, nullptr, 0, nullptr, nullptr, B, H, W,
@@ -675,14 +807,14 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     FU_TRY(launch_maxpool2_bwd(c->prec, K.g_pooled, pv.y, pv.a, pv.b, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level],
                                pv.cout, s));
   } else if (K.kind == BK_UP) {
-    Conv& sk = c->blk[K.skip].c[1];
-    Conv& pv = c->blk[i - 1].c[1];
+    const Feat sk = level_feat(c, K.skip);
+    const Feat pv = low_feat(c, i);
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
-    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, sk.gy, sk.cout, K.g_up, v.cin_real - sk.cout, nullptr, nullptr,
+    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, sk.gy, sk.C, K.g_up, v.cin_real - sk.C, nullptr, nullptr,
                           B, H, W, s));
-    const int h = c->Hs[pv.level], w = c->Ws[pv.level];
+    const int h = c->Hs[K.level + 1], w = c->Ws[K.level + 1];
     if (c->cfg.bilinear) {
-      FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, h, w, pv.cout, H, W, K.upt, s));
+      FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, h, w, pv.C, H, W, K.upt, s));
     } else {
       FU_TRY(launch_zero_border(c->prec, K.g_up, B, h, w, K.ct_cout, H, W, s));      // F.pad region carries no gradient
       int ndbp = 0;
@@ -699,6 +831,14 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   return 0;
 }
 
+// backward order: 0 = head, 1..4 = up4..up1, [5 = the fusion convs], then down4..inc of the last encoder ... the first
+int num_backward_blocks(const fu_ctx* c) { return 5 + (c->fusion ? 1 : 0) + 5 * c->nE; }
+int backward_block_index(const fu_ctx* c, int block) {
+  if (block <= 4) return c->nb - block;                       // nb-1 (up4) ... nb-4 (up1)
+  const int k = block - 5 - (c->fusion ? 1 : 0);              // 0 .. 5*nE-1 over the encoders, last encoder first
+  return 5 * c->nE - 1 - k;
+}
+
 int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStream_t s, bool join) {
   const fu_config& f = c->cfg;
   const int B = c->last_batch;
@@ -707,12 +847,22 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
       FU_TRY(launch_dlogits_from_nchw(dlogits_ext, c->dlogits, f.n_classes, B, f.height, f.width, s));
     else
       FU_REQUIRE(c->have_loss, "fu_backward: no dlogits given and no fu_loss_* call since the last forward");
-    Conv& last = c->blk[8].c[1];
+    Conv& last = c->blk[c->nb - 1].c[1];
     FU_TRY(launch_head_bwd(c->prec, c->dlogits, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
                            (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s));
     return 0;
   }
-  const int i = 9 - block;
+  if (c->fusion && block == 5) {
+    // shares the slab and the bias-gradient partials with the side stream's weight-gradient chain: join it first (the
+    // encoders' chains that follow are ordered behind this block by their ev_gy events)
+    if (c->side && c->side_mode != 0) {
+      FU_HIP_CHECK(hipEventRecord(c->ev_blk, c->side));
+      FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_blk, 0));
+      c->wg_pending[0] = c->wg_pending[1] = false;
+    }
+    return fuse_backward(c, B, s);
+  }
+  const int i = backward_block_index(c, block);
   FU_TRY(backward_conv(c, i, 1, B, s));
   FU_TRY(backward_conv(c, i, 0, B, s));
   if (c->side && c->side_mode != 0 && join) {   // the block's gradients are complete (for the caller's all-reduce / Adam) once the side stream is
@@ -733,15 +883,17 @@ int check_fwd_args(fu_ctx* c, const float* x, int batch) {
 
 double conv_flops(fu_ctx* c, bool train) {
   double fwd = 0.0, first = 0.0;
-  for (int i = 0; i < 9; ++i)
+  for (int i = 0; i < c->nb; ++i)
     for (int j = 0; j < 2; ++j) {
       const Conv& v = c->blk[i].c[j];
       const double fl = 2.0 * 9 * v.cin_real * v.cout * c->Hs[v.level] * c->Ws[v.level];
-      if (i == 0 && j == 0) first = fl;
+      if (c->blk[i].role == 0 && j == 0) first += fl;      // the encoders' first convs have no data gradient
       fwd += fl;
     }
+  for (int l = 0; l < 5 && c->fusion; ++l)                   // the 1x1 fusion convs (the MACs they need, not the 3x3 run)
+    fwd += 2.0 * c->nE * c->fuse[l].C * c->fuse[l].C * c->Hs[l] * c->Ws[l];
   if (!c->cfg.bilinear)
-    for (int i = 5; i < 9; ++i) {
+    for (int i = 5 * c->nE; i < c->nb; ++i) {
       const Block& K = c->blk[i];
       fwd += 2.0 * 4 * K.ct_cin * K.ct_cout * c->Hs[K.level + 1] * c->Ws[K.level + 1];
     }
@@ -773,6 +925,16 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   FU_REQUIRE(cfg->bilinear || b == 64, "bilinear=0 exists only at base_channels 64 (the reference's UNetDecoder "
              "channel plan is inconsistent for bilinear=False, unet.py:176-183)");
   FU_REQUIRE(cfg->precision == FU_F32 || b >= 8, "bf16 precision needs base_channels >= 8");
+  FU_REQUIRE(cfg->n_encoders >= 0 && cfg->n_encoders <= FU_MAX_ENCODERS, "n_encoders must be 0..%d", FU_MAX_ENCODERS);
+  if (cfg->n_encoders >= 1) {
+    FU_REQUIRE(cfg->bilinear, "late fusion exists only with bilinear upsampling (lf_model.py:38)");
+    int sum = 0;
+    for (int e = 0; e < cfg->n_encoders; ++e) {
+      FU_REQUIRE(cfg->enc_channels[e] >= 1, "enc_channels[%d] must be >= 1", e);
+      sum += cfg->enc_channels[e];
+    }
+    FU_REQUIRE(sum == cfg->n_channels, "enc_channels sum to %d, n_channels is %d", sum, cfg->n_channels);
+  }
   FU_HIP_CHECK(hipSetDevice(cfg->device));
   fu_ctx* c = new (std::nothrow) fu_ctx();
   FU_REQUIRE(c, "out of host memory");
@@ -841,7 +1003,7 @@ int fu_bind_buffers(fu_ctx* c, float* params, float* grads, float* running_mean,
   FU_REQUIRE(c && params && running_mean && running_var && num_batches_tracked, "fu_bind_buffers: null buffer");
   c->P = params; c->G = grads; c->RM = running_mean; c->RV = running_var; c->NBT = num_batches_tracked;
   c->packed_dirty = true;
-  c->pack_tab.n = 0;
+  c->pack_tabs.clear();
   return FU_OK;
 }
 int fu_params_changed(fu_ctx* c) {
@@ -907,11 +1069,12 @@ int fu_loss_bce_dice(fu_ctx* c, const int64_t* target, int ignore_index, float d
   return FU_OK;
 }
 
-int fu_num_blocks(const fu_ctx* c) { (void)c; return 10; }
+int fu_num_blocks(const fu_ctx* c) { return c ? num_backward_blocks(c) : 0; }
 
 int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stream) {
   FU_REQUIRE(c, "null context");
-  FU_REQUIRE(block >= 0 && block < 10, "fu_backward_block: block %d outside 0..9", block);
+  FU_REQUIRE(block >= 0 && block < num_backward_blocks(c), "fu_backward_block: block %d outside 0..%d", block,
+             num_backward_blocks(c) - 1);
   if (!(c->last_batch > 0 && c->fwd_training)) {
     set_error("fu_backward: the last fu_forward was not a training forward");
     return FU_ERR_STATE;
@@ -946,15 +1109,17 @@ int fu_backward(fu_ctx* c, const float* dlogits, fu_stream stream) {
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
   SyncScope sc(c, true);
   // whole backward: the side stream (weight gradients) is joined once, after the last block
-  for (int b = 0; b < 10; ++b) FU_TRY(backward_block_impl(c, b, dlogits, (hipStream_t)stream, b == 9));
+  const int nblk = num_backward_blocks(c);
+  for (int b = 0; b < nblk; ++b) FU_TRY(backward_block_impl(c, b, dlogits, (hipStream_t)stream, b == nblk - 1));
   return FU_OK;
 }
 
 int fu_block_param_range(const fu_ctx* c, int block, int64_t* flat_offset, int64_t* numel) {
-  FU_REQUIRE(c && block >= 0 && block < 10, "fu_block_param_range: bad block %d", block);
+  FU_REQUIRE(c && block >= 0 && block < num_backward_blocks(c), "fu_block_param_range: bad block %d", block);
   int first, count;
   if (block == 0) { first = c->p_outw; count = 2; }
-  else { const Block& K = c->blk[9 - block]; first = K.first_param; count = K.num_params; }
+  else if (c->fusion && block == 5) { first = c->fuse[0].p_w; count = 10; }
+  else { const Block& K = c->blk[backward_block_index(c, block)]; first = K.first_param; count = K.num_params; }
   const ParamInfo& a = c->params[first];
   const ParamInfo& z = c->params[first + count - 1];
   if (flat_offset) *flat_offset = a.off;

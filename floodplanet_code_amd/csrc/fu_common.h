@@ -214,7 +214,8 @@ int launch_pack_conv3x3_bf16(const float* w_oihw, int Cout, int cin_real, int ci
                              hipStream_t s);
 extern int g_bf16_force_cfg;
 
-int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s);
+int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s,
+                        int src_channels = 0, int src_channel_offset = 0);
 int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H, int W, int c_pad, hipStream_t s);
 
 // BN: finalize forward statistics.  partials [nTiles][C][2]; count = B*H*W.
@@ -266,6 +267,10 @@ int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, floa
                                 hipStream_t s);
 int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t s);
 int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hipStream_t s);
+int launch_copy_channels(Prec p, const void* src, int srcC, int src_off, const float* a, const float* b, void* dst,
+                         int dstC, int dst_off, int C, int64_t npix, hipStream_t s);
+int launch_center_to_w3(const float* w, int64_t n, float* w3, hipStream_t s);
+int launch_center_from_w3(const float* dw3, int64_t n, float* dw, hipStream_t s);
 
 // head: 1x1 conv + bias on relu(a*y+b); logits fp32 NHWC [npix][ncls] (+ optional NCHW copy)
 int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const float* w, const float* bias, int C,

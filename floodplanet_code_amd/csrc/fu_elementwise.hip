@@ -59,14 +59,14 @@ static inline int grid_for(int64_t work, int block, int cap = 8192) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ dst, int C, int HW, int cpad,
-                               int64_t total) {
+                               int64_t total, int srcC) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % cpad);
     const int64_t bp = idx / cpad;
     const int p = (int)(bp % HW);
     const int64_t b = bp / HW;
-    const float v = (c < C) ? src[(b * C + c) * HW + p] : 0.f;
+    const float v = (c < C) ? src[(b * srcC + c) * HW + p] : 0.f;   // srcC: channels per sample of the source
     ElemIO<T>::store1(dst + idx, v);
   }
 }
@@ -84,13 +84,18 @@ __global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ ds
   }
 }
 
-int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s) {
+int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s,
+                        int src_channels, int src_channel_offset) {
+  // C channels starting at src_channel_offset of an NCHW tensor with src_channels per sample (0 = C: the whole tensor)
   const int64_t total = (int64_t)B * H * W * c_pad;
   const int g = grid_for(total, 256);
+  const int srcC = src_channels > 0 ? src_channels : C;
+  src += (int64_t)src_channel_offset * H * W;
   if (p == PREC_F32)
-    hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, C, H * W, c_pad, total);
+    hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, C, H * W, c_pad, total, srcC);
   else
-    hipLaunchKernelGGL(k_nchw_to_nhwc<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, C, H * W, c_pad, total);
+    hipLaunchKernelGGL(k_nchw_to_nhwc<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, C, H * W, c_pad, total,
+                       srcC);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -836,6 +841,64 @@ int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t
 int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hipStream_t s) {
   const int64_t total = (int64_t)Cin * Cout * 4;
   hipLaunchKernelGGL(k_convT_grad_from_w3, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, dw3, Cin, Cout, dw, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Late fusion (lf_model.py:78-90): channel-window copies between NHWC tensors, with the producer's BN + ReLU applied on
+// the way in (concat of the encoders' features) or plain (split of the concat's gradient), and the 1x1 fusion weight
+// embedded as the centre tap of a 3x3 one (the fusion conv runs on the 3x3 kernels for now: 9x the MACs it needs).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void k_copy_channels(const T* __restrict__ src, int srcC, int src_off, const float* __restrict__ a,
+                                const float* __restrict__ b, T* __restrict__ dst, int dstC, int dst_off, int C,
+                                int64_t npix) {
+  const int vec = C / V;
+  const int64_t total = npix * vec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % vec);
+    const int64_t p = idx / vec;
+    float v[V];
+    VecIO<T>::load(src + p * srcC + src_off + cv * V, v);
+    if (a != nullptr) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = bn_act(a[cv * V + k], v[k], b[cv * V + k]);
+    }
+    VecIO<T>::store(dst + p * dstC + dst_off + cv * V, v);
+  }
+}
+int launch_copy_channels(Prec p, const void* src, int srcC, int src_off, const float* a, const float* b, void* dst,
+                         int dstC, int dst_off, int C, int64_t npix, hipStream_t s) {
+  const int V = p == PREC_F32 ? 4 : 8;
+  FU_REQUIRE(C % V == 0 && srcC % V == 0 && dstC % V == 0 && src_off % V == 0 && dst_off % V == 0,
+             "copy_channels: channel counts / offsets must be multiples of %d", V);
+  const int g = grid_for(npix * (C / V), 256);
+  if (p == PREC_F32)
+    hipLaunchKernelGGL((k_copy_channels<float, 4>), dim3(g), dim3(256), 0, s, (const float*)src, srcC, src_off, a, b,
+                       (float*)dst, dstC, dst_off, C, npix);
+  else
+    hipLaunchKernelGGL((k_copy_channels<bf16_t, 8>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, srcC, src_off, a, b,
+                       (bf16_t*)dst, dstC, dst_off, C, npix);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_center_to_w3(const float* __restrict__ w, float* __restrict__ w3, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 9; i += (int64_t)gridDim.x * blockDim.x)
+    w3[i] = (i % 9 == 4) ? w[i / 9] : 0.f;
+}
+__global__ void k_center_from_w3(const float* __restrict__ dw3, float* __restrict__ dw, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dw[i] = dw3[i * 9 + 4];
+}
+int launch_center_to_w3(const float* w, int64_t n, float* w3, hipStream_t s) {
+  hipLaunchKernelGGL(k_center_to_w3, dim3(grid_for(n * 9, 256, 4096)), dim3(256), 0, s, w, w3, n);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_center_from_w3(const float* dw3, int64_t n, float* dw, hipStream_t s) {
+  hipLaunchKernelGGL(k_center_from_w3, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, dw3, dw, n);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -43,7 +43,8 @@
 extern "C" {
 #endif
 
-#define FU_ABI_VERSION 1
+#define FU_ABI_VERSION 2
+#define FU_MAX_ENCODERS 6
 
 typedef struct fu_ctx fu_ctx;
 typedef void* fu_stream; /* hipStream_t */
@@ -76,6 +77,13 @@ typedef struct fu_config {
   int32_t height, width; /* tile size (any size >= 16; odd sizes take the F.pad path of unet.py:57-62) */
   int32_t precision;     /* enum fu_precision */
   int32_t device;        /* HIP device ordinal */
+  /* Late fusion (lf_model.py:29-92, feat_fusion='concat_conv'): n_encoders >= 1 builds one UNetEncoder per input over
+   * consecutive channel windows of the input (enc_channels[e] channels each, summing to n_channels, in the order
+   * lf_model.py:58-76 gathers them), five 1x1 fusion convs (n_encoders*fs -> fs at fs = 64,128,256,512,512 for
+   * base 64) and one UNetDecoder.  Parameter names: encoders.<e>.*, concat_convs.<level>.*, decoder.* (the host side
+   * maps <e> to the reference's ModuleDict keys).  0 = the plain UNet.  Needs bilinear = 1. */
+  int32_t n_encoders;
+  int32_t enc_channels[FU_MAX_ENCODERS];
 } fu_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
