@@ -71,6 +71,39 @@ def channel_plan(n_channels: int, base: int, bilinear: bool):
     return e, outs
 
 
+def _build_encoder(root: nn.Module, n_channels: int, base: int, bilinear: bool):
+    """inc, down1..down4 of UNetEncoder (unet.py:143-149) attached to `root`; construction order == reference so that
+    torch.manual_seed(s) gives identical weights."""
+    e, _ = channel_plan(n_channels, base, bilinear)
+    root.inc = _double_conv(n_channels, e[0], e[0])
+    for i in range(1, 5):
+        d = _Holder()
+        mp = _Holder()
+        mp.add_module("1", _double_conv(e[i - 1], e[i], e[i]))
+        d.add_module("maxpool_conv", mp)
+        root.add_module(f"down{i}", d)
+
+
+def _build_decoder(root: nn.Module, n_classes: int, base: int, bilinear: bool):
+    """up1..up4, outc of UNetDecoder (unet.py:176-184, channel_factor 1) attached to `root`."""
+    e, outs = channel_plan(1, base, bilinear)
+    low = e[4]
+    for k in range(4):
+        u = _Holder()
+        skip = e[3 - k]
+        if bilinear:
+            cin = low + skip
+            u.add_module("conv", _double_conv(cin, cin // 2, outs[k]))
+        else:
+            u.add_module("up", _ConvParams(low, low // 2, 2, transposed=True))
+            u.add_module("conv", _double_conv(low // 2 + skip, outs[k], outs[k]))
+        root.add_module(f"up{k + 1}", u)
+        low = outs[k]
+    oc = _Holder()
+    oc.add_module("conv", _ConvParams(base, n_classes, 1))
+    root.outc = oc
+
+
 class HipUNet(nn.Module):
     """Drop-in for ``UNet(n_channels, n_classes, bilinear=True)`` running on MI355X HIP kernels.
 
@@ -84,30 +117,7 @@ class HipUNet(nn.Module):
             raise ValueError(f"unknown precision {precision!r}")
         self.n_channels, self.n_classes, self.bilinear = n_channels, n_classes, bilinear
         self.base_channels, self.precision = base_channels, precision
-        e, outs = channel_plan(n_channels, base_channels, bilinear)
-        # construction order == reference (unet.py:88-98) so torch.manual_seed(s) gives identical weights
-        self.inc = _double_conv(n_channels, e[0], e[0])
-        for i in range(1, 5):
-            d = _Holder()
-            mp = _Holder()
-            mp.add_module("1", _double_conv(e[i - 1], e[i], e[i]))
-            d.add_module("maxpool_conv", mp)
-            self.add_module(f"down{i}", d)
-        low = e[4]
-        for k in range(4):
-            u = _Holder()
-            skip = e[3 - k]
-            if bilinear:
-                cin = low + skip
-                u.add_module("conv", _double_conv(cin, cin // 2, outs[k]))
-            else:
-                u.add_module("up", _ConvParams(low, low // 2, 2, transposed=True))
-                u.add_module("conv", _double_conv(low // 2 + skip, outs[k], outs[k]))
-            self.add_module(f"up{k + 1}", u)
-            low = outs[k]
-        oc = _Holder()
-        oc.add_module("conv", _ConvParams(base_channels, n_classes, 1))
-        self.outc = oc
+        self._build_tree()
 
         self._table: List[Tuple[str, nn.Parameter, int, int]] = []  # name, param, offset, numel
         off = 0
@@ -132,6 +142,19 @@ class HipUNet(nn.Module):
         self._confusion: Optional[torch.Tensor] = None
         self._exact = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+
+    def _build_tree(self):
+        n_channels, base_channels, bilinear, n_classes = self.n_channels, self.base_channels, self.bilinear, self.n_classes
+        _build_encoder(self, n_channels, base_channels, bilinear)
+        _build_decoder(self, n_classes, base_channels, bilinear)
+
+    def _enc_config(self):
+        """(n_encoders, enc_channels) of fu_config: 0 = the plain UNet."""
+        return 0, []
+
+    def _c_param_name(self, name: str) -> str:
+        """state_dict key -> the C side's canonical name (identity for the plain UNet)."""
+        return name
 
     # ---------------------------------------------------------------- flat storage
     def _mark_dirty(self):
@@ -202,8 +225,10 @@ class HipUNet(nn.Module):
             return self._ctx
         self._destroy_ctx()
         lib = _lib.load()
+        n_enc, enc_ch = self._enc_config()
         cfg = FuConfig(C.sizeof(FuConfig), self.n_channels, self.n_classes, self.base_channels, int(self.bilinear),
-                       B, H, W, _lib.PRECISIONS[self.precision], device.index if device.index is not None else 0)
+                       B, H, W, _lib.PRECISIONS[self.precision], device.index if device.index is not None else 0,
+                       n_enc, (C.c_int32 * 6)(*(list(enc_ch) + [0] * (6 - len(enc_ch)))))
         h = C.c_void_p()
         check(lib.fu_create(C.byref(cfg), C.byref(h)))
         self._ctx = h
@@ -261,7 +286,8 @@ class HipUNet(nn.Module):
         off = C.c_int64()
         for i, (pname, p, poff, _) in enumerate(self._table):
             check(lib.fu_param_info(self._ctx, i, C.byref(name), C.byref(ndim), shape, C.byref(off)))
-            if name.value.decode() != pname or off.value != poff or tuple(shape[:ndim.value]) != tuple(p.shape):
+            if name.value.decode() != self._c_param_name(pname) or off.value != poff or \
+                    tuple(shape[:ndim.value]) != tuple(p.shape):
                 raise RuntimeError(f"parameter {i}: python {pname}{tuple(p.shape)}@{poff} vs C "
                                    f"{name.value.decode()}{tuple(shape[:ndim.value])}@{off.value}")
 

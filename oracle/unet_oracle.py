@@ -445,3 +445,114 @@ def conv_flops_per_tile(n_channels, H, W, base=64, bilinear=True, n_classes=3):
         fwd += 2.0 * 9 * cin * mid * h * w + 2.0 * 9 * mid * cout * h * w
     fwd += 2.0 * base * n_classes * H * W
     return fwd, 3.0 * fwd - first
+
+
+# --------------------------------------------------------------------------- #
+# Late fusion (st_water_seg/models/lf_model.py:29-92, feat_fusion='concat_conv')
+# --------------------------------------------------------------------------- #
+LF_FORWARD_ORDER = ("ms_image", "dem", "slope", "preflood", "pre_post_difference", "hand")   # lf_model.py:56-76
+LF_BATCH_KEY = {"ms_image": "image"}                                                          # encoder name -> batch key
+
+
+def lf_param_spec(in_channels: "OrderedDict[str, int]", n_classes: int, base: int = 64):
+    """state_dict key -> (shape, kind) in the reference's registration order (lf_model.py:31-45): encoders in
+    in_channels order, decoder, concat_convs."""
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    for name, ch in in_channels.items():
+        for k, v in param_spec(ch, n_classes, base, True).items():
+            if k.startswith(("inc.", "down")):
+                spec[f"encoders.{name}.{k}"] = v
+    for k, v in param_spec(1, n_classes, base, True).items():
+        if k.startswith(("up", "outc.")):
+            spec[f"decoder.{k}"] = v
+    n = len(in_channels)
+    for l, fs in enumerate([base, base * 2, base * 4, base * 8, base * 8]):        # [64,128,256,512,512] at base 64
+        spec[f"concat_convs.{l}.weight"] = ((fs, fs * n, 1, 1), "conv_w")
+        spec[f"concat_convs.{l}.bias"] = ((fs,), "conv_b")
+    return spec
+
+
+def lf_make_state(in_channels, n_classes: int, base: int = 64, seed: int = 0):
+    """Deterministic parameters for the late-fusion net (same generator and value ranges as make_state)."""
+    st: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for stream, (name, (shape, kind)) in enumerate(lf_param_spec(in_channels, n_classes, base).items()):
+        n = int(np.prod(shape)) if len(shape) else 1
+        u = hash_uniform(n, seed + 1000, stream)
+        if kind == "conv_w":
+            v = (u * 2.0 - 1.0) / math.sqrt(shape[1] * shape[2] * shape[3])
+        elif kind == "conv_b":
+            v = (u * 2.0 - 1.0) * 0.1
+        elif kind == "bn_w":
+            v = 0.5 + u
+        elif kind == "bn_b":
+            v = (u - 0.5) * 0.4
+        elif kind == "bn_rm":
+            v = np.zeros(n)
+        elif kind == "bn_rv":
+            v = np.ones(n)
+        elif kind == "bn_nbt":
+            st[name] = torch.zeros((), dtype=torch.int64)
+            continue
+        else:
+            raise AssertionError(kind)
+        st[name] = torch.from_numpy(v.astype(np.float32)).reshape(shape).clone()
+    return st
+
+
+def _encoder_forward(st, x, prefix, training):
+    """unet.py:151-159: [x1..x5]."""
+    feats = [_double_conv(x, st, f"{prefix}inc.double_conv", training)]
+    for i in range(1, 5):
+        feats.append(_double_conv(F.max_pool2d(feats[-1], 2), st, f"{prefix}down{i}.maxpool_conv.1.double_conv",
+                                  training))
+    return feats
+
+
+def _decoder_forward(st, feats, prefix, training):
+    """unet.py:186-192 (bilinear)."""
+    cur = feats[4]
+    for k in range(4):
+        skip = feats[3 - k]
+        up = F.interpolate(cur, scale_factor=2, mode="bilinear", align_corners=True)
+        dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]
+        up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        cur = _double_conv(torch.cat([skip, up], dim=1), st, f"{prefix}up{k + 1}.conv.double_conv", training)
+    return F.conv2d(cur, st[f"{prefix}outc.conv.weight"], st[f"{prefix}outc.conv.bias"])
+
+
+def lf_forward(st, batch, in_channels, training: bool):
+    """lf_model.py:54-92: encode every input, concatenate the features level by level in the fixed order, fuse each
+    level with its 1x1 conv, decode."""
+    feats = None
+    for name in LF_FORWARD_ORDER:
+        if name not in in_channels:
+            continue
+        f = _encoder_forward(st, batch[LF_BATCH_KEY.get(name, name)], f"encoders.{name}.", training)
+        feats = f if feats is None else [torch.concat([a, b], dim=1) for a, b in zip(feats, f)]
+    fused = [F.conv2d(x, st[f"concat_convs.{l}.weight"], st[f"concat_convs.{l}.bias"]) for l, x in enumerate(feats)]
+    return _decoder_forward(st, fused, "decoder.", training)
+
+
+def lf_loss_and_grads(st, batch, in_channels, ignore_index, training=True):
+    names = trainable_names(st)
+    leaves, work = {}, dict(st)
+    for k in names:
+        leaves[k] = st[k].detach().clone().requires_grad_(True)
+        work[k] = leaves[k]
+    logits = lf_forward(work, batch, in_channels, training)
+    loss = ce_loss(logits, batch["target"], ignore_index)
+    loss.backward()
+    grads = {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])) for k in names}
+    return logits.detach(), loss.detach(), grads
+
+
+def lf_train_step(st, opt, batch, in_channels, ignore_index, lr):
+    logits, loss, grads = lf_loss_and_grads(st, batch, in_channels, ignore_index, True)
+    with torch.no_grad():
+        adam_update(st, grads, opt, lr)
+    return logits, loss, grads
+
+
+def lf_eval_forward(st, batch, in_channels):
+    with torch.no_grad():
+        return lf_forward(dict(st), batch, in_channels, False)

@@ -31,8 +31,20 @@ def load_golden(name):
     return meta, z
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+def golden_names(late_fusion=False):
+    """UNet training-step fixtures (oracle/make_golden.py) or the late-fusion ones (oracle/make_golden_lf.py: lf_*)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("lf_") == late_fusion)
+
+
+def lf_case_inputs(meta):
+    """Batch, ordered in_channels and initial state of a late-fusion golden case from the closed-form generator."""
+    from collections import OrderedDict
+    from oracle import unet_oracle as O
+    in_ch = OrderedDict((k, v) for k, v in meta["in_channels"])
+    extras = tuple(k for k in O.LF_FORWARD_ORDER if k in in_ch and k != "ms_image")
+    batch = O.make_batch(meta["B"], in_ch["ms_image"], meta["H"], meta["W"], seed=meta["data_seed"], extra=extras)
+    st = O.lf_make_state(in_ch, meta["n_classes"], meta["base"], seed=meta["param_seed"])
+    return batch, in_ch, st
 
 
 def case_inputs(meta):

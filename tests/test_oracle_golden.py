@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import case_inputs, golden_names, is_dead_bias, load_golden
+from conftest import case_inputs, golden_names, is_dead_bias, lf_case_inputs, load_golden
 from oracle import unet_oracle as O
 
 FAST = [n for n in golden_names() if n.startswith("s_")] + ["m_base8_64", "f_full_c8_32"]
@@ -62,3 +62,37 @@ def test_param_spec_counts():
     n = sum(int(np.prod(s)) if len(s) else 1 for _, (s, kind) in spec.items() if O.is_trainable(kind))
     assert n == 17270403 and len(spec) == 128
     assert sum(1 for _, (_, kind) in spec.items() if O.is_trainable(kind)) == 74
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names(late_fusion=True) if n != "lf_f_full_32"])
+def test_late_fusion_oracle_matches_reference_fixture(name):
+    """oracle lf_* (lf_model.py:29-92 restated) against the fixtures made from the reference's own UNetEncoder /
+    UNetDecoder classes (oracle/make_golden_lf.py; bit-exact there)."""
+    torch.set_num_threads(4)
+    meta, z = load_golden(name)
+    batch, in_ch, st = lf_case_inputs(meta)
+    lr = meta["lr"]
+    opt = O.new_adam_state(st)
+    logits1, loss1, grads1 = O.lf_train_step(st, opt, batch, in_ch, 0, lr)
+    np.testing.assert_allclose(logits1.numpy(), z["logits1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(loss1.item(), z["loss1"].item(), rtol=1e-5, atol=1e-6)
+    for j, k in enumerate(meta["names"]):
+        if is_dead_bias(k):
+            continue
+        g, s = grads1[k].double(), z["grad_stats1"][j]
+        assert abs(g.pow(2).sum().sqrt().item() - s[2]) <= 1e-4 * max(s[2], 1e-6) + 1e-7, k
+        if f"g1_{j}" in z.files:
+            ref = torch.from_numpy(z[f"g1_{j}"]).double()
+            assert (g - ref).norm() <= 1e-4 * ref.norm() + 1e-9, k
+    _, loss2, _ = O.lf_train_step(st, opt, batch, in_ch, 0, lr)
+    np.testing.assert_allclose(loss2.item(), z["loss2"].item(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(O.lf_eval_forward(st, batch, in_ch).numpy(), z["eval_logits"], rtol=0, atol=2e-3)
+
+
+def test_late_fusion_param_spec():
+    from collections import OrderedDict
+    spec = O.lf_param_spec(OrderedDict([("ms_image", 4), ("dem", 1), ("slope", 1)]), 3)
+    keys = list(spec)
+    assert keys[0] == "encoders.ms_image.inc.double_conv.0.weight" and keys[-1] == "concat_convs.4.bias"
+    assert spec["concat_convs.3.weight"][0] == (512, 1536, 1, 1) and spec["concat_convs.4.weight"][0] == (512, 1536, 1, 1)
+    assert "decoder.outc.conv.weight" in spec and "decoder.inc.double_conv.0.weight" not in spec
