@@ -4,15 +4,8 @@
 forwards positionally exactly like the reference, so ``fit.py:66-73`` / ``predict.py:164-171`` /
 ``infer.py:86-93`` can import this module in place of ``st_water_seg.models``."""
 from .ef_model import EarlyFusionModel
+from .lf_model import LateFusionModel
 from .water_seg_model import WaterSegmentationModel
-
-
-class LateFusionModel:
-    """st_water_seg/models/lf_model.py is outside this build's hot-path scope."""
-
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('lf_model (LateFusionModel) is not part of the MI355X hot path yet; '
-                                  'use ms_model or ef_model')
 
 
 MODELS = {

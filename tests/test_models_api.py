@@ -82,3 +82,35 @@ def test_metrics_formulas():
     assert torch.equal(m.confusion(), torch.from_numpy(conf))
     ref = O.metrics_from_counts(conf)
     assert abs(ref["MulticlassAccuracy"] - 0.5) < 1e-9
+
+
+def test_late_fusion_plugin_surface():
+    """lf_model.py:9-92: ctor signature incl. feat_fusion, state_dict keys at the top level of the module, seeded init in
+    the reference's construction order (encoders in in_channels order, decoder, concat_convs)."""
+    from collections import OrderedDict
+    from floodplanet_code_amd.models import LateFusionModel
+    in_ch = OrderedDict([("dem", 1), ("ms_image", 4)])
+    torch.manual_seed(3)
+    m = build_model("lf_model", in_ch, 3, 1e-4, 50, None, 0, optimizer_name="adam", feat_fusion="concat_conv",
+                    base_channels=8)
+    assert isinstance(m, LateFusionModel) and m.feat_fusion == "concat_conv"
+    spec = O.lf_param_spec(in_ch, 3, 8)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(spec.keys())
+    for k, (shape, _) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    # the first module the reference constructs is encoders['dem'].inc's first conv (in_channels order)
+    torch.manual_seed(3)
+    first = torch.nn.Conv2d(1, 8, 3, padding=1)
+    assert torch.equal(sd["encoders.dem.inc.double_conv.0.weight"], first.weight)
+    # forward order of the inputs (lf_model.py:56-76): image first, whatever the dict order
+    assert m.model.encoder_names == ["ms_image", "dem"] and m.model.n_channels == 5
+    # a reference-style checkpoint loads by name
+    st = O.lf_make_state(in_ch, 3, 8, seed=1)
+    missing = m.load_state_dict(st, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(m.state_dict()["concat_convs.2.weight"], st["concat_convs.2.weight"])
+    with pytest.raises(NotImplementedError):
+        LateFusionModel(in_ch, 3, 1e-4, ignore_index=0, feat_fusion="attention")
+    with pytest.raises(KeyError):
+        LateFusionModel({"dem": 1}, 3, 1e-4, ignore_index=0)
