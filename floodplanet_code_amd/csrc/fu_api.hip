@@ -690,7 +690,7 @@ int fuse_forward(fu_ctx* c, int B, hipStream_t s) {
       Conv& v = c->blk[5 * e + l].c[1];
       FU_TRY(launch_copy_channels(c->prec, v.y, v.cout, 0, v.a, v.b, F.cat, Ccat, e * F.C, F.C, npix, s));
     }
-    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0};
+    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0, true};   // 1x1: only the centre tap of wf is non-zero
     FU_TRY(launch_conv3x3(c->prec, in, F.wf, P(c, F.p_b), F.y, F.C, nullptr, 0, nullptr, nullptr, B, H, W, s));
   }
   return 0;
@@ -710,7 +710,7 @@ int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
     FU_TRY(launch_conv3x3_wgrad(c->prec, in, F.gy, F.C, c->slab, F.dw3, Ccat, c->db_part, ndbp, G(c, F.p_b), B, H, W,
                                 s));
     FU_TRY(launch_center_from_w3(F.dw3, (int64_t)F.C * Ccat, G(c, F.p_w), s));
-    ConvIn gin{F.gy, F.C, nullptr, nullptr, nullptr, 0};
+    ConvIn gin{F.gy, F.C, nullptr, nullptr, nullptr, 0, true};    // the flipped 3x3 of a centre tap is a centre tap
     FU_TRY(launch_conv3x3(c->prec, gin, F.wd, nullptr, F.gcat, Ccat, nullptr, 0, nullptr, nullptr, B, H, W, s));
     for (int e = 0; e < c->nE; ++e) {
       Conv& v = c->blk[5 * e + l].c[1];

@@ -172,6 +172,7 @@ struct ConvIn {              // the (virtual) input of a 3x3 convolution
   const float* a0;           // optional BN scale for src0: x = relu(a0*src0 + b0)
   const float* b0;
   const void* src1; int C1;  // next C1 channels, taken as they are (may be null/0)
+  bool center_only = false;  // the packed weights are a 1x1 conv embedded as the centre tap (late-fusion convs)
 };
 
 // conv as implicit GEMM: out[p][n] = sum_{tap,c} in[p+tap][c] * wpk[tap][c][n] (+bias[n])

@@ -60,6 +60,7 @@ struct BConvP {
   int C0, C1, Cin, N, D0, D1, B, H, W, tilesX, tilesY, nPix, nCo;
   unsigned rcp_nPix, rcp_tilesX, rcp_tilesY;   // fast path: floor(2^32 / d) + 1 (0 for d == 1)
   unsigned long long* dbg;   // optional s_memtime stamps per workgroup (tools/stamp_test.py; FU_CONV_STAMPS builds)
+  int center_only;           // 1: every tap but the centre one of wpk is zero (embedded 1x1): the fast kernel skips them
 };
 
 // aligned-shape fast path (fu_conv_bf16_fast.hip)

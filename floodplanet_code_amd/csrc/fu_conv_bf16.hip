@@ -374,6 +374,7 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.N = D0 + D1; P.D0 = D0; P.D1 = D1;
   P.B = B; P.H = H; P.W = W;
   P.dbg = g_conv_dbg;
+  P.center_only = in.center_only ? 1 : 0;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
   FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);

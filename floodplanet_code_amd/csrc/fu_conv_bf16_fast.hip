@@ -35,31 +35,35 @@
 
 namespace fu {
 
-template <int NTW>
+// TAPS = 9: the 3x3 convolution.  TAPS = 1: only the centre tap of the same packed [9][N][Cin] weights, i.e. a 1x1
+// convolution (the late-fusion convs, whose 1x1 weight is embedded as the centre tap): 2 k-steps per chunk instead of 18.
+template <int NTW, int TAPS = 9>
 struct FCfg {
   static constexpr int NT = 256, TW = 16, TH = 16, BN = 32 * NTW, KC = 32, KCP = 40;
   static constexpr int HWd = TW + 2, NHP = (TH + 2) * HWd;
   static constexpr int A_UNITS = NHP * 4;                              // 16-byte units (8 channels) per chunk
   static constexpr int A_ITERS = (A_UNITS + NT - 1) / NT, A_FULL = A_UNITS / NT, A_REM = A_UNITS % NT;
-  static constexpr int W_UNITS = 9 * BN * 4;
+  static constexpr int W_UNITS = TAPS * BN * 4;
   static constexpr int W_ITERS = (W_UNITS + NT - 1) / NT, W_FULL = W_UNITS / NT, W_REM = W_UNITS % NT;
   static constexpr int ROWS_PER_IT = NT / 4;                           // LDS rows (pixels / weight rows) per iteration
   static constexpr int TAPS_PER_IT = ROWS_PER_IT / BN;                 // 1 (BN = 64) or 2 (BN = 32)
   static constexpr int AB_FLOATS = 2 * 1024;                           // BN scale / shift of source 0
-  static constexpr int SMEM_BYTES = (NHP + 9 * BN) * KCP * 2 + AB_FLOATS * 4;
+  static constexpr int SMEM_BYTES = (NHP + TAPS * BN) * KCP * 2 + AB_FLOATS * 4;
+  static constexpr int NSTEPS = 2 * TAPS;                              // k-steps (16 channels) per chunk
+  static constexpr int TAP0 = TAPS == 1 ? 4 : 0;                       // first tap of the packed weights that is used
   static_assert(W_REM % 64 == 0, "the ragged weight iteration must be wave-uniform");
 };
 
-template <int NTW>
+template <int NTW, int TAPS = 9>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
-  using Cfg = FCfg<NTW>;
+  using Cfg = FCfg<NTW, TAPS>;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, KC = Cfg::KC, KCP = Cfg::KCP, NT = Cfg::NT;
   constexpr int HWd = Cfg::HWd, NHP = Cfg::NHP, A_ITERS = Cfg::A_ITERS, W_ITERS = Cfg::W_ITERS;
   constexpr int RPI = Cfg::ROWS_PER_IT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);            // [NHP][KCP]
-  bf16_t* sW = sA + NHP * KCP;                                 // [9][BN][KCP]
-  float* sAB = reinterpret_cast<float*>(sW + 9 * BN * KCP);    // [2][1024] BN scale / shift of source 0
+  bf16_t* sW = sA + NHP * KCP;                                 // [TAPS][BN][KCP]
+  float* sAB = reinterpret_cast<float*>(sW + TAPS * BN * KCP); // [2][1024] BN scale / shift of source 0
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = 64-pixel slice of the tile (uniform)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   const int wrow = srow;
   const int wco = wrow & (BN - 1), wtsub = wrow / BN;
   const bool w_ok = n0 + wco < P.N;
-  const unsigned w_off = (w_ok ? (unsigned)((wtsub * P.N + n0 + wco) * P.Cin) * 2u : 0u) + 16u * aq;
+  const unsigned w_off = (w_ok ? (unsigned)(((wtsub + Cfg::TAP0) * P.N + n0 + wco) * P.Cin) * 2u : 0u) + 16u * aq;
   const unsigned w_step = (unsigned)(Cfg::TAPS_PER_IT * P.N * P.Cin) * 2u;
 
   uint4 ra[A_ITERS];
@@ -230,8 +234,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     bf16x8 af[NB][2], bfr[NB][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
-      constexpr int tap = st >> 1, ks = st & 1;
-      constexpr int toff = ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16;
+      constexpr int tap = st >> 1, ks = st & 1;                       // tap = index inside sW
+      constexpr int gtap = tap + Cfg::TAP0;                           // its position in the 3x3 window
+      constexpr int toff = ((gtap / 3) * HWd + (gtap % 3)) * KCP + ks * 16;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
 #pragma unroll
@@ -239,9 +244,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
         bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
     };
     static_for<0, FD>([&](auto Sc) { load_frags(Sc, std::integral_constant<int, decltype(Sc)::value % NB>{}); });
-    static_for<0, 18>([&](auto S) {
+    static_for<0, Cfg::NSTEPS>([&](auto S) {
       constexpr int st = decltype(S)::value, buf = st % NB;
-      if constexpr (st + FD < 18) {
+      if constexpr (st + FD < Cfg::NSTEPS) {
         load_frags(std::integral_constant<int, st + FD>{}, std::integral_constant<int, (st + FD) % NB>{});
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
       }
@@ -276,7 +281,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // next chunk starts the second source
 #if FU_FAST_LOADS_PER_STEP > 0
     load_begin(k0 + KC);
-    mfma_block(std::integral_constant<int, FU_FAST_LOADS_PER_STEP>{});
+    // all A_ITERS + W_ITERS loads must fit in the block's k-steps: 2 per step over 18 steps, 4 over the 2 of a 1x1
+    constexpr int LPS = TAPS == 1 ? (A_ITERS + W_ITERS + 1) / 2 : FU_FAST_LOADS_PER_STEP;
+    static_assert(LPS * Cfg::NSTEPS >= A_ITERS + W_ITERS, "next chunk's loads do not fit behind the k-steps");
+    mfma_block(std::integral_constant<int, LPS>{});
 #else
     load_chunk(k0 + KC);                                      // raw loads stay in flight under the MFMA block
     mfma_block(std::integral_constant<int, 0>{});
@@ -498,9 +506,9 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P) {
   return true;
 }
 
-template <int NTW>
+template <int NTW, int TAPS = 9>
 static int launch_fast_cfg(BConvP& P, hipStream_t s) {
-  using Cfg = FCfg<NTW>;
+  using Cfg = FCfg<NTW, TAPS>;
   P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
   P.rcp_nPix = host_rcp(P.nPix); P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
@@ -508,14 +516,14 @@ static int launch_fast_cfg(BConvP& P, hipStream_t s) {
              P.nPix, P.nCo);
   static bool attr_set = false;
   if (!attr_set) {
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_fast<NTW>),
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_fast<NTW, TAPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
   const ProfSlot ps = g_prof_slot;
   g_prof_slot = ProfSlot();
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW, TAPS>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;
@@ -526,6 +534,7 @@ static int launch_fast_cfg(BConvP& P, hipStream_t s) {
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
   const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
   const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
+  if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, s) : launch_fast_cfg<1, 1>(P, s);
   return wide ? launch_fast_cfg<2>(P, s) : launch_fast_cfg<1>(P, s);
 }
 
