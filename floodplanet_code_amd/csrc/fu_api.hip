@@ -706,7 +706,7 @@ int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
     const int64_t npix = (int64_t)B * H * W;
     int ndbp = 0;
     FU_TRY(launch_channel_partial_sums(c->prec, F.gy, F.C, npix, c->db_part, &ndbp, s));
-    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0};
+    ConvIn in{F.cat, Ccat, nullptr, nullptr, nullptr, 0, true};   // only the centre tap of dw3 is computed (and read)
     FU_TRY(launch_conv3x3_wgrad(c->prec, in, F.gy, F.C, c->slab, F.dw3, Ccat, c->db_part, ndbp, G(c, F.p_b), B, H, W,
                                 s));
     FU_TRY(launch_center_from_w3(F.dw3, (int64_t)F.C * Ccat, G(c, F.p_w), s));

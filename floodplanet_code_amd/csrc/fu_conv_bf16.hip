@@ -364,6 +364,7 @@ static int launch_cfg(BConvP& P, hipStream_t s) {
 
 int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64 tile, 2 = 256x32 tile
 int g_bf16_force_general = 0;   // testing hook (fu_test_force_general_conv): skip the aligned-shape fast kernel
+int g_bf16_force_full_taps = 0; // testing hook (fu_test_force_full_taps): embedded 1x1 convs run all nine taps
 unsigned long long* g_conv_dbg = nullptr;
 
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
@@ -374,7 +375,7 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.C0 = in.C0; P.C1 = in.src1 ? in.C1 : 0; P.Cin = P.C0 + P.C1; P.N = D0 + D1; P.D0 = D0; P.D1 = D1;
   P.B = B; P.H = H; P.W = W;
   P.dbg = g_conv_dbg;
-  P.center_only = in.center_only ? 1 : 0;
+  P.center_only = (in.center_only && !g_bf16_force_full_taps) ? 1 : 0;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
   FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);
@@ -435,7 +436,9 @@ struct WCfg {
   static constexpr int SMEM_BYTES = (NHP * RSX + NPX * RSD) * 2 + 2 * CI_T * 4;
 };
 
-template <int WMI, int PTH>
+// TAPS = 9: the 3x3 weight gradient.  TAPS = 1: only its centre tap (the embedded 1x1 fusion convs of the late-fusion
+// net): 8 MFMAs per stage instead of 72; the other eight tap slabs are left unwritten and must not be read.
+template <int WMI, int PTH, int TAPS = 9>
 __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
   using Cfg = WCfg<WMI, PTH>;
   constexpr int CI_T = Cfg::CI_T, CO_T = Cfg::CO_T, NT = Cfg::NT, HWd = Cfg::HWd, NHP = Cfg::NHP, NPX = Cfg::NPX;
@@ -456,9 +459,9 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
   const int ciT = t / P.nCo, coT = t - ciT * P.nCo;
   const int ci0 = ciT * CI_T, co0 = coT * CO_T;
 
-  f32x16 acc[9];
+  f32x16 acc[TAPS];
 #pragma unroll
-  for (int k = 0; k < 9; ++k)
+  for (int k = 0; k < TAPS; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
@@ -598,19 +601,34 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
       const bf16_t* bd = sD + (r * 16 + tr_px) * RSD + ni * 32 + tr_ch;
       Bf[r & 3] = tr_frag(bd, bd + 4 * RSD);
     };
-    loadB(std::integral_constant<int, 0>{});
-    loadA(std::integral_constant<int, 0>{});
-    static_for<0, 3 * (PTH + 2)>([&](auto S) {
-      constexpr int st = decltype(S)::value, hr = st / 3, dx = st % 3;
-      if constexpr (st + 1 < 3 * (PTH + 2)) loadA(std::integral_constant<int, st + 1>{});
-      if constexpr (dx == 0 && hr + 1 < PTH) loadB(std::integral_constant<int, hr + 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, 3>([&](auto DY) {
-        constexpr int dy = decltype(DY)::value, r = hr - dy;
-        if constexpr (r >= 0 && r < PTH)
-          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+    if constexpr (TAPS == 9) {
+      loadB(std::integral_constant<int, 0>{});
+      loadA(std::integral_constant<int, 0>{});
+      static_for<0, 3 * (PTH + 2)>([&](auto S) {
+        constexpr int st = decltype(S)::value, hr = st / 3, dx = st % 3;
+        if constexpr (st + 1 < 3 * (PTH + 2)) loadA(std::integral_constant<int, st + 1>{});
+        if constexpr (dx == 0 && hr + 1 < PTH) loadB(std::integral_constant<int, hr + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 3>([&](auto DY) {
+          constexpr int dy = decltype(DY)::value, r = hr - dy;
+          if constexpr (r >= 0 && r < PTH)
+            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+        });
       });
-    });
+    } else {
+      // centre tap only: pixel row r pairs halo row r + 1, column shift 1 (stage index 3 (r + 1) + 1 of loadA)
+      loadB(std::integral_constant<int, 0>{});
+      loadA(std::integral_constant<int, 4>{});
+      static_for<0, PTH>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        if constexpr (r + 1 < PTH) {
+          loadA(std::integral_constant<int, 3 * (r + 2) + 1>{});
+          loadB(std::integral_constant<int, r + 1>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(3 * (r + 1) + 1) & 1], Bf[r & 3], acc[0], 0, 0, 0);
+      });
+    }
 #ifdef FU_CONV_STAMPS
     const unsigned long long tD = __builtin_amdgcn_s_memtime();
     if (pt > pt0) { tStage += tB - tA; tIssue += tC - tB; tMfma += tD - tC; }
@@ -622,11 +640,12 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
   const int co = co0 + ni * 32 + l31;
   if (co < P.Cout) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int t = 0; t < TAPS; ++t) {
+      const int tap = TAPS == 9 ? t : 4;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[tap][r];
+        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[t][r];
       }
     }
   }
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
                         int ndb, float* db, hipStream_t s);
 
-template <int WMI, int PTH>
+template <int WMI, int PTH, int TAPS = 9>
 static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
   using Cfg = WCfg<WMI, PTH>;
   P.tilesX = ceil_div(P.W, Cfg::PTW); P.tilesY = ceil_div(P.H, PTH);
@@ -911,14 +930,14 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
   P.S = ceil_div(P.nPix, P.perSplit);
   static bool attr_set = false;
   if (!attr_set) {
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16<WMI, PTH>),
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16<WMI, PTH, TAPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
   const ProfSlot ps = g_prof_slot;
   g_prof_slot = ProfSlot();
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL((k_wgrad_bf16<WMI, PTH>), dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  hipLaunchKernelGGL((k_wgrad_bf16<WMI, PTH, TAPS>), dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;
@@ -977,7 +996,11 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   P.dbg = g_conv_dbg;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0 && Cout % 8 == 0, "wgrad_bf16: channel counts must be multiples of 8");
   int st;
-  if (P.Cin > 64 && !g_wgrad_force_lockstep) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  // embedded 1x1 (late-fusion convs): the stage is all staging, so the lock-step kernel (all 8 waves stage together) wins
+  // over the ping-pong one; the eight unwritten tap slabs reach only taps of dw_oihw that the caller never reads
+  if (in.center_only && !g_bf16_force_full_taps && P.Cin > 64) st = launch_wgrad_cfg<4, 8, 1>(P, 256, s);
+  else if (in.center_only && !g_bf16_force_full_taps) st = launch_wgrad_cfg<2, 8, 1>(P, 512, s);
+  else if (P.Cin > 64 && !g_wgrad_force_lockstep) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
   else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);
   else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;
@@ -988,4 +1011,5 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
 
 extern "C" void fu_test_force_general_conv(int on) { fu::g_bf16_force_general = on; }
 extern "C" void fu_test_force_lockstep_wgrad(int on) { fu::g_wgrad_force_lockstep = on; }
+extern "C" void fu_test_force_full_taps(int on) { fu::g_bf16_force_full_taps = on; }
 extern "C" void fu_debug_set_conv_stamps(void* p) { fu::g_conv_dbg = (unsigned long long*)p; }

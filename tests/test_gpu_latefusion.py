@@ -167,3 +167,30 @@ def test_late_fusion_plugin_training_and_validation_steps():
     with torch.no_grad():
         logits = m(dbatch)
     assert logits.shape == (meta["B"], 3, meta["H"], meta["W"]) and torch.isfinite(logits).all()
+
+
+def test_one_tap_fusion_kernel_is_bit_identical_to_the_nine_tap_run():
+    """bf16, full width (the fusion convs take the aligned-shape fast kernel): logits and every gradient with the 1-tap
+    instantiation == the same step with all nine taps of the embedded weight."""
+    from floodplanet_code_amd import _lib
+    in_ch = OrderedDict([("ms_image", 8), ("dem", 1)])
+    st = O.lf_make_state(in_ch, 3, 64, seed=2)
+    batch = O.make_batch(2, 8, 64, 48, seed=4, extra=("dem",))
+    lib = _lib.load()
+    outs = []
+    for full in (0, 1):
+        net = HipLateFusion(in_ch, 3, base_channels=64, precision="bf16")
+        net.load_state_dict(st)
+        net = net.to(DEV).train()
+        x, tgt = fused_input(batch, net).to(DEV), batch["target"].to(DEV)
+        lib.fu_test_force_full_taps(full)
+        try:
+            loss, logits = net.loss(x, tgt, 0, return_logits=True)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            lib.fu_test_force_full_taps(0)
+        outs.append((logits.detach().cpu(), net.flat_grads().detach().cpu().clone()))
+    assert torch.isfinite(outs[0][0]).all() and outs[0][1].abs().max() > 0
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
