@@ -129,3 +129,66 @@ def test_exact_mode_two_ranks_reproduce_one_device_with_the_joint_batch(tmp_path
     d = (res["params"] - net.flat_parameters().cpu()).abs().max().item()
     assert d <= 2.5e-3, d      # +-lr sign flips on noise-level gradients
     # and it is NOT what DDP semantics give: per-rank statistics differ visibly on such small batches
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# late fusion (lf_model.py): the same trainer, more blocks (head, up4..up1, fusion, 2 x 5 encoder blocks)
+def _lf_parts():
+    from collections import OrderedDict
+    from oracle import unet_oracle as O
+    in_ch = OrderedDict([("ms_image", 8), ("dem", 1)])
+    return in_ch, O.lf_make_state(in_ch, 3, 16, seed=0)
+
+
+def _lf_batch(rank_seed):
+    from oracle import unet_oracle as O
+    b = O.make_batch(2, 8, 64, 64, seed=40 + rank_seed, n_label_values=2, extra=("dem",))
+    return torch.cat([b["image"], b["dem"]], dim=1), b["target"]
+
+
+def _worker_lf_exact(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from floodplanet_code_amd.distributed import DataParallelTrainer
+    from floodplanet_code_amd.latefusion import HipLateFusion
+    dev = torch.device("cuda:0")
+    in_ch, st = _lf_parts()
+    net = HipLateFusion(in_ch, 3, base_channels=16)
+    net.load_state_dict(st)
+    net.to(dev).train()
+    tr = DataParallelTrainer(net, lr=1e-3, world_size=world, rank=rank, cap_bytes=256 << 10, exact=True)
+    x, t = _lf_batch(rank)
+    loss = tr.step(x.to(dev), t.to(dev), 0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"loss": loss.cpu(), "grads": net.flat_grads().cpu(), "params": net.flat_parameters().cpu(),
+                    "rm": net._flat_rm.cpu(), "n_buckets": len(tr._reducer.buckets)}, out_path)
+    dist.destroy_process_group()
+
+
+def test_late_fusion_exact_mode_two_ranks_reproduce_one_device(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "lf_exact.pt")
+    mp.spawn(_worker_lf_exact, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["n_buckets"] >= 3                           # the 16 backward blocks really were bucketed
+
+    from floodplanet_code_amd.latefusion import HipLateFusion
+    dev = torch.device("cuda:0")
+    in_ch, st = _lf_parts()
+    net = HipLateFusion(in_ch, 3, base_channels=16)
+    net.load_state_dict(st)
+    net.to(dev).train()
+    (x0, t0), (x1, t1) = _lf_batch(0), _lf_batch(1)
+    loss = net.train_step(torch.cat([x0, x1]).to(dev), torch.cat([t0, t1]).to(dev), 0)
+    grads = net.flat_grads().clone().cpu()
+    net.adam_step(1e-3, 1)
+    torch.cuda.synchronize()
+    assert abs(res["loss"].item() - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    assert torch.allclose(res["rm"], net._flat_rm.cpu(), rtol=1e-5, atol=1e-6)
+    rel = ((res["grads"] - grads).norm() / grads.norm()).item()
+    assert rel <= 2e-3, rel
+    assert (res["params"] - net.flat_parameters().cpu()).abs().max().item() <= 2.5e-3
