@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
                     help="bf16 = BASELINE.json configs[1] (default); f32 = the 1e-4 parity mode")
+    ap.add_argument("--model", default="unet", choices=["unet", "lf"],
+                    help="unet = the headline workload (ms_model / ef_model); lf = the late-fusion net (lf_model.py): "
+                         "--channels image bands + --aux one-band auxiliary inputs, one encoder each")
+    ap.add_argument("--aux", type=int, default=1, help="--model lf: number of one-band auxiliary inputs (dem, slope, ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true",
                     help="skip the extra un-timed pass that measures the dominant kernel without the side stream")
@@ -59,20 +63,35 @@ def host_cores():
     return min(n, int(os.environ.get("FU_BENCH_CPU_THREADS", "16")))
 
 
-def cpu_baseline(channels, size, cpu_batch, cpu_steps):
+AUX_NAMES = ["dem", "slope", "preflood", "pre_post_difference", "hand"]
+
+
+def lf_in_channels(channels, aux):
+    from collections import OrderedDict
+    return OrderedDict([("ms_image", channels)] + [(k, 1) for k in AUX_NAMES[:aux]])
+
+
+def cpu_baseline(channels, size, cpu_batch, cpu_steps, model="unet", aux=1):
     """The oracle (kind 'port': torch-CPU restatement of the reference step, pinned bit-exactly against the
     reference in the dev container) on this box's host cores, bounded sample."""
     from oracle import unet_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    st = O.make_state(channels, 3, 64, True, seed=0, nontrivial_bn=False)
+    if model == "lf":
+        in_ch = lf_in_channels(channels, aux)
+        st = O.lf_make_state(in_ch, 3, 64, seed=0)
+        batch = O.make_batch(cpu_batch, channels, size, size, seed=1, extra=tuple(AUX_NAMES[:aux]))
+        step = lambda: O.lf_train_step(st, opt, batch, in_ch, 0, 1e-4)      # noqa: E731
+    else:
+        st = O.make_state(channels, 3, 64, True, seed=0, nontrivial_bn=False)
+        batch = O.make_batch(cpu_batch, channels, size, size, seed=1)
+        step = lambda: O.train_step(st, opt, batch, 0, 1e-4)                # noqa: E731
     opt = O.new_adam_state(st)
-    batch = O.make_batch(cpu_batch, channels, size, size, seed=1)
-    O.train_step(st, opt, batch, 0, 1e-4)  # warm-up
+    step()  # warm-up
     times = []
     for _ in range(cpu_steps):
         t0 = time.perf_counter()
-        O.train_step(st, opt, batch, 0, 1e-4)
+        step()
         times.append(time.perf_counter() - t0)
     best = min(times)
     return {"value": round(cpu_batch / best, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
@@ -113,12 +132,17 @@ def main():
     if os.environ.get("FU_BENCH_GENERAL_CONV") == "1":   # A/B knob: general bf16 conv kernel instead of the fast one
         _lib.load().fu_test_force_general_conv(1)
     torch.manual_seed(0)
-    net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
+    if args.model == "lf":
+        from floodplanet_code_amd.latefusion import HipLateFusion
+        net = HipLateFusion(lf_in_channels(args.channels, args.aux), 3, base_channels=64, precision=precision)
+        net = net.to(dev).train()
+    else:
+        net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
     trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank)
 
     B, Cc, S = args.batch, args.channels, args.size
     g = torch.Generator(device=dev).manual_seed(1 + rank)
-    x = torch.rand(B, Cc, S, S, device=dev, generator=g)
+    x = torch.rand(B, net.n_channels, S, S, device=dev, generator=g)   # (lf: the image and the aux inputs side by side)
     # blob-like binary labels, ignore_index 0 as in conf/config.yaml:26
     yy, xx = torch.meshgrid(torch.arange(S, device=dev), torch.arange(S, device=dev), indexing="ij")
     ph = torch.rand(B, 3, device=dev, generator=g) * 6.28
@@ -137,14 +161,23 @@ def main():
     for _ in range(args.warmup):
         trainer.step(x, target, 0)
     lib = _lib.load()
-    _lib.check(lib.fu_profile_enable(net._ctx, 1))
+    # HIP events around every conv / wgrad launch serialise the kernel boundaries (~2 us per pair: 6.39 -> 6.66 ms per
+    # step when every step is timed, same box), so the live roofline measurement samples every EVENT_STRIDE-th step of
+    # the timed region; FU_BENCH_EVENT_STRIDE=1 times them all, 0 none
+    stride = int(os.environ.get("FU_BENCH_EVENT_STRIDE", "8"))
+    sampled = 0
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        on = stride > 0 and i % stride == 0
+        if on:
+            _lib.check(lib.fu_profile_enable(net._ctx, 1 if sampled == 0 else 2))
+            sampled += 1
         loss = trainer.step(x, target, 0)
+        if on:
+            _lib.check(lib.fu_profile_enable(net._ctx, 0))
     sync_all()
     dt = time.perf_counter() - t0
-    _lib.check(lib.fu_profile_enable(net._ctx, 0))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,7 +202,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", f"r1_pmc_{args.dtype}.json")) as fh:
             pm = json.load(fh)
-        if best and best["kernel"] in pm and B == 16 and S == 256 and Cc == 8:
+        if best and best["kernel"] in pm and B == 16 and S == 256 and Cc == 8 and args.model == "unet":
             traffic = pm[best["kernel"]]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -195,7 +228,8 @@ def main():
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": best["kernel"], "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "launches": best["launches"], "avg_launch_ms": round(best["ms"] / best["launches"], 4),
+                "launches": best["launches"], "event_timed_steps": sampled,
+                "avg_launch_ms": round(best["ms"] / best["launches"], 4),
                 "avg_launch_gflop": round(best["flops"] / best["launches"] / 1e9, 3),
                 "whole_step_frac_of_conv_roofline": round(value / world * train_fl / 1e12 / peak, 4)}
         if serial is not None:
@@ -203,18 +237,23 @@ def main():
             roof["frac_serial"] = round(serial / peak, 4)
 
     out = {
-        "metric": f"training tiles/sec ({S}x{S}x{Cc}ch UNet)", "value": round(value, 3), "unit": "tiles/s",
+        "metric": (f"training tiles/sec ({S}x{S}x{Cc}ch UNet)" if args.model == "unet" else
+                   f"training tiles/sec ({S}x{S}, {Cc}ch image + {args.aux} aux, late fusion)"),
+        "value": round(value, 3), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"UNet depth-4 (17.27M params), {Cc}-band {S}x{S} tiles, batch {B}/GPU, "
-                               f"fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN",
+        "config": {"workload": (f"UNet depth-4 (17.27M params), {Cc}-band {S}x{S} tiles, batch {B}/GPU, "
+                                f"fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN" if args.model == "unet" else
+                                f"LateFusion ({1 + args.aux} UNet encoders + 1x1 fusion + decoder, "
+                                f"{net._total / 1e6:.2f}M params), {Cc}-band image + {args.aux} aux {S}x{S} tiles, "
+                                f"batch {B}/GPU, fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_tile": round(train_fl / 1e9, 3)},
         "loss": round(float(loss.item()), 6),
         "roofline": roof,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(Cc, S, args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(Cc, S, args.cpu_batch, args.cpu_steps, args.model, args.aux)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1169,9 +1169,11 @@ int fu_profile_enable(fu_ctx* c, int enable) {
       FU_HIP_CHECK(hipEventCreate(&e));
       pr.pool.push_back(e);
     }
-    pr.next = 0;
-    pr.recs.clear();
-    pr.overflow = false;
+    if (enable != 2) {          // 2 = resume: keep the records of the earlier enabled stretches
+      pr.next = 0;
+      pr.recs.clear();
+      pr.overflow = false;
+    }
     pr.on = true;
   } else {
     pr.on = false;

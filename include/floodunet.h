@@ -200,8 +200,10 @@ enum fu_kernel_class {
   FU_K_WGRAD = 1,   /* weight-gradient kernel (without its slab reduce) */
   FU_K_NUM = 2
 };
-/* enable != 0: allocate/reset the event pool and time every launch of the classes above on the stream it is
- * launched on; enable == 0: stop.  fu_profile_read synchronises the device and sums what was recorded. */
+/* enable == 1: allocate/reset the event pool and time every launch of the classes above on the stream it is
+ * launched on; enable == 2: resume without dropping what was recorded (sampling some steps of a run: an event pair
+ * around every launch costs ~2 us of serialisation each, 4 % of the bench step when every step is timed);
+ * enable == 0: stop.  fu_profile_read synchronises the device and sums what was recorded. */
 int fu_profile_enable(fu_ctx* ctx, int enable);
 int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
                     const char** kernel_name);
