@@ -109,6 +109,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C floodplanet_code_amd/csrc`). "
             "There is no CPU / PyTorch fallback for this path.")
+    # torch first: its libamdhip64 must be the process's HIP runtime before ours is resolved (same SONAME, so the
+    # loader then binds libfloodunet.so to it).  The device pointers and stream handles that cross the C ABI come from
+    # torch; with the library loaded first the process ends up with /opt/rocm's runtime beside torch's bundled one and
+    # hipSetDevice fails with "no ROCm-capable device" (seen when build() and smoke() ran in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
