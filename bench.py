@@ -235,6 +235,10 @@ def main():
         if serial is not None:
             roof["achieved_serial"] = round(serial, 3)
             roof["frac_serial"] = round(serial / peak, 4)
+        if traffic:   # HBM bytes per launch (PMC passes) over the live launch duration, against the 8 TB/s HBM3E peak
+            gbps = traffic / (best["ms"] / best["launches"] * 1e-3) / 1e9
+            roof["hbm_gbps"] = round(gbps, 1)
+            roof["hbm_frac_of_8tbps"] = round(gbps / 8000.0, 4)
 
     out = {
         "metric": (f"training tiles/sec ({S}x{S}x{Cc}ch UNet)" if args.model == "unet" else
