@@ -192,3 +192,52 @@ def test_late_fusion_exact_mode_two_ranks_reproduce_one_device(tmp_path):
     rel = ((res["grads"] - grads).norm() / grads.norm()).item()
     assert rel <= 2e-3, rel
     assert (res["params"] - net.flat_parameters().cpu()).abs().max().item() <= 2.5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL machinery with the one GPU of the box: a single `nccl` rank drives the block-wise backward exactly as N ranks do
+# (side stream in caller-join mode, fu_backward_join at bucket ends, asynchronous all-reduce on ProcessGroupNCCL's
+# stream, Work.wait before Adam); with one rank the all-reduce is the identity, so the parameters must equal the
+# plain fu_backward path bit for bit.
+def _worker_nccl_one_rank(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import floodplanet_code_amd.distributed as D
+    from floodplanet_code_amd.unet import HipUNet
+    from oracle import unet_oracle as O
+    b = O.make_batch(4, 8, 64, 64, seed=33)
+    x, t = b["image"].to(dev), b["target"].to(dev)
+    res = {}
+    for tag, force in (("blocks", True), ("plain", False)):
+        net = HipUNet(8, 3, base_channels=32, precision="bf16")
+        net.load_state_dict(O.make_state(8, 3, 32, True, seed=3))
+        net.to(dev).train()
+        D._FORCE_BLOCKS = force
+        tr = D.DataParallelTrainer(net, lr=1e-3, world_size=1, rank=0, cap_bytes=512 << 10)
+        if force:
+            net._forward_raw(x, True, want_logits=False)        # creates the context: block ranges need it
+            tr._reducer = D.BucketedReducer(net.block_ranges(), 2, None, tr.cap_bytes)   # world 2: do all-reduce
+            res["n_buckets"] = len(tr._reducer.buckets)
+            res["side_mode"] = tr._side_mode()
+        for _ in range(3):
+            loss = tr.step(x, t, 0)
+        torch.cuda.synchronize()
+        res[tag] = (net.flat_parameters().cpu().clone(), float(loss.item()))
+    D._FORCE_BLOCKS = False
+    torch.save(res, out_path)
+    dist.destroy_process_group()
+
+
+def test_block_wise_backward_under_one_nccl_rank_equals_plain_backward(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "nccl1.pt")
+    mp.spawn(_worker_nccl_one_rank, args=(1, port, out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res["n_buckets"] >= 3 and res["side_mode"] == 2          # nccl: side stream on, caller joins
+    assert res["blocks"][1] == res["plain"][1]
+    assert torch.equal(res["blocks"][0], res["plain"][0])
