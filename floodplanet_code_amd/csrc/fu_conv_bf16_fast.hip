@@ -37,27 +37,36 @@ namespace fu {
 
 // TAPS = 9: the 3x3 convolution.  TAPS = 1: only the centre tap of the same packed [9][N][Cin] weights, i.e. a 1x1
 // convolution (the late-fusion convs, whose 1x1 weight is embedded as the centre tap): 2 k-steps per chunk instead of 18.
-template <int NTW, int TAPS = 9>
+// MT = m-tiles (2 image rows x 16 columns) per wave: 2 -> 16x16-pixel workgroup tile, 4 -> 16 wide x 32 high (512
+// pixels).  KC = input channels per LDS chunk (32 or 16).  The tall tile with 16-channel chunks (MT 4, KC 16) stages
+// 2376 16-byte units per 288 MFMAs instead of 3600 and reads 0.75 fragments per MFMA instead of 1, in 57 KB of LDS
+// (two workgroups per CU as before).
+template <int NTW, int TAPS = 9, int MT_ = 2, int KC_ = 32>
 struct FCfg {
-  static constexpr int NT = 256, TW = 16, TH = 16, BN = 32 * NTW, KC = 32, KCP = 40;
+  static constexpr int NT = 256, TW = 16, MT = MT_, TH = 8 * MT, BN = 32 * NTW, KC = KC_, KCP = KC + 8;
+  static constexpr int UPR = KC / 8;                                   // 16-byte units per LDS row
+  static constexpr int KSTEPS = KC / 16;                               // MFMA k-steps per tap and chunk
   static constexpr int HWd = TW + 2, NHP = (TH + 2) * HWd;
-  static constexpr int A_UNITS = NHP * 4;                              // 16-byte units (8 channels) per chunk
+  static constexpr int A_UNITS = NHP * UPR;                            // 16-byte units (8 channels) per chunk
   static constexpr int A_ITERS = (A_UNITS + NT - 1) / NT, A_FULL = A_UNITS / NT, A_REM = A_UNITS % NT;
-  static constexpr int W_UNITS = TAPS * BN * 4;
+  static constexpr int W_UNITS = TAPS * BN * UPR;
   static constexpr int W_ITERS = (W_UNITS + NT - 1) / NT, W_FULL = W_UNITS / NT, W_REM = W_UNITS % NT;
-  static constexpr int ROWS_PER_IT = NT / 4;                           // LDS rows (pixels / weight rows) per iteration
-  static constexpr int TAPS_PER_IT = ROWS_PER_IT / BN;                 // 1 (BN = 64) or 2 (BN = 32)
+  static constexpr int ROWS_PER_IT = NT / UPR;                         // LDS rows (pixels / weight rows) per iteration
+  static constexpr int TAPS_PER_IT = ROWS_PER_IT / BN;                 // 1, 2 or 4
+  static_assert(ROWS_PER_IT % BN == 0 && (KC == 32 || KC == 16) && (MT == 2 || MT == 4), "unsupported tile");
   static constexpr int AB_FLOATS = 2 * 1024;                           // BN scale / shift of source 0
   static constexpr int SMEM_BYTES = (NHP + TAPS * BN) * KCP * 2 + AB_FLOATS * 4;
-  static constexpr int NSTEPS = 2 * TAPS;                              // k-steps (16 channels) per chunk
+  static constexpr int NSTEPS = KSTEPS * TAPS;                         // k-steps (16 channels) per chunk
   static constexpr int TAP0 = TAPS == 1 ? 4 : 0;                       // first tap of the packed weights that is used
   static_assert(W_REM % 64 == 0, "the ragged weight iteration must be wave-uniform");
 };
 
-template <int NTW, int TAPS = 9>
-__global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
-  using Cfg = FCfg<NTW, TAPS>;
+template <int NTW, int TAPS = 9, int MT = 2, int KCH = 32>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BConvP P) {   // tall tile: <= 256 registers
+
+  using Cfg = FCfg<NTW, TAPS, MT, KCH>;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, KC = Cfg::KC, KCP = Cfg::KCP, NT = Cfg::NT;
+  constexpr int UPR = Cfg::UPR;
   constexpr int HWd = Cfg::HWd, NHP = Cfg::NHP, A_ITERS = Cfg::A_ITERS, W_ITERS = Cfg::W_ITERS;
   constexpr int RPI = Cfg::ROWS_PER_IT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -86,16 +95,21 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   // ---- staging slots.  Slot `it` of thread t is 16-byte unit u = t + 256 it: halo pixel u >> 2, channel octet t & 3.
   //      a_off = byte offset of that unit inside the CURRENT source at channel 0 (recomputed once, at the switch to
   //      the second source); out-of-image pixels load the nearest image pixel and are zeroed when written to LDS.
-  const int aq = tid & 3;
+  const int aq = tid & (UPR - 1);
   // LDS row of this thread's staging units.  A ds_write_b128 is served in groups of 8 lanes = 2 rows x 4 units; with
   // 80-byte rows, consecutive rows (20 dwords apart) put unit 3 of one row on the banks of unit 0 of the next (2-way
   // conflict on every write: ~20 % of the LDS-active cycles, profiles/r1_pmc_bf16.json).  Rows 4 apart (80 dwords = 16 mod
   // 32) do not collide, so the two rows of a group are r and r + 4: bits 0 and 2 of the row index are swapped.
 #if FU_FAST_ROWPERM
-  const int srow_lin = tid >> 2;
-  const int srow = (srow_lin & ~7) | ((srow_lin & 1) << 2) | ((srow_lin >> 1) & 3);
+  const int srow_lin = tid / UPR;
+  // 80-byte rows, 4 units per row: the two rows of an 8-lane write group must be 4 apart (bits 0 and 2 swapped).
+  // 48-byte rows, 2 units per row (KC = 16): the four rows of a group must be 2 apart -- rows r, r+2, r+4, r+6 put
+  // their 8 units on 8 distinct 16-byte slots of the 128-byte bank window (48 r mod 128 = 0, 96, 64, 32); the low
+  // three bits are rotated.
+  const int srow = UPR == 4 ? ((srow_lin & ~7) | ((srow_lin & 1) << 2) | ((srow_lin >> 1) & 3))
+                            : ((srow_lin & ~7) | ((srow_lin & 3) << 1) | ((srow_lin >> 2) & 1));
 #else
-  const int srow = tid >> 2;
+  const int srow = tid / UPR;
 #endif
   unsigned a_off[A_ITERS];
   unsigned a_ok = 0;
@@ -191,9 +205,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     });
   };
 
-  f32x16 acc[2][NTW];
+  f32x16 acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -201,11 +215,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 
   // fragment base offsets (bf16 elements).  m-tile = 2 image rows x 16 columns; lanes 16..31 (second row) take their
   // columns ROTATED by HWd mod 16 so that the 16 lanes of every ds_read_b128 group hit 16 distinct bank slots.
-  int aoff[2], boff[NTW];
+  int aoff[MT], boff[NTW];
   const int mrow = l31 >> 4;
   const int mcol = mrow ? ((l31 - 16 - (HWd & 15)) & 15) : l31;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) aoff[mt] = (((wm * 2 + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
+  for (int mt = 0; mt < MT; ++mt) aoff[mt] = (((wm * MT + mt) * 2 + mrow) * HWd + mcol) * KCP + 8 * lh;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) boff[nt] = (nt * 32 + l31) * KCP + 8 * lh;
 
@@ -230,15 +244,17 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
   // s+1 are requested from LDS before the MFMAs of step s are issued.
   auto mfma_block = [&](auto Lc) {
     constexpr int LOADS = decltype(Lc)::value;   // 0: none; n: next chunk's loads, n per k-step behind its MFMAs
-    constexpr int FD = FU_FAST_FRAG_DIST, NB = FD + 1;
-    bf16x8 af[NB][2], bfr[NB][NTW];
+    // (tall tile: 128 accumulator registers; a second fragment buffer would not fit in 256 registers -- its 8 MFMAs per
+    //  k-step and the co-resident wave cover the LDS latency instead of a one-step prefetch)
+    constexpr int FD = MT == 4 ? 0 : FU_FAST_FRAG_DIST, NB = FD + 1;
+    bf16x8 af[NB][MT], bfr[NB][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
-      constexpr int tap = st >> 1, ks = st & 1;                       // tap = index inside sW
+      constexpr int tap = st / Cfg::KSTEPS, ks = st % Cfg::KSTEPS;    // tap = index inside sW
       constexpr int gtap = tap + Cfg::TAP0;                           // its position in the 3x3 window
       constexpr int toff = ((gtap / 3) * HWd + (gtap % 3)) * KCP + ks * 16;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
+      for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
         bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
@@ -282,7 +298,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 #if FU_FAST_LOADS_PER_STEP > 0
     load_begin(k0 + KC);
     // all A_ITERS + W_ITERS loads must fit in the block's k-steps: 2 per step over 18 steps, 4 over the 2 of a 1x1
-    constexpr int LPS = TAPS == 1 ? (A_ITERS + W_ITERS + 1) / 2 : FU_FAST_LOADS_PER_STEP;
+    constexpr int LPS = Cfg::NSTEPS * FU_FAST_LOADS_PER_STEP >= A_ITERS + W_ITERS
+                            ? FU_FAST_LOADS_PER_STEP : (A_ITERS + W_ITERS + Cfg::NSTEPS - 1) / Cfg::NSTEPS;
     static_assert(LPS * Cfg::NSTEPS >= A_ITERS + W_ITERS, "next chunk's loads do not fit behind the k-steps");
     mfma_block(std::integral_constant<int, LPS>{});
 #else
@@ -314,14 +331,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 
   auto epilogue = [&](auto Fc, auto Bc) {
     constexpr bool FULL = decltype(Fc)::value, BIAS = decltype(Bc)::value;
-    unsigned sb[2][4];     // byte offset of the store of (mt, g) from dbase
+    unsigned sb[MT][4];    // byte offset of the store of (mt, g) from dbase
     unsigned sok = 0;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int p = qj + 8 * g + 4 * lh;
-        const int oy = y0 + (wm * 2 + mt) * 2 + (g >> 1);
+        const int oy = y0 + (wm * MT + mt) * 2 + (g >> 1);
         const int ox = x0 + ((g >> 1) ? ((p - 16 - (HWd & 15)) & 15) : p);
         sb[mt][g] = ((unsigned)((bb * P.H + oy) * P.W + ox) * (unsigned)dstride + (unsigned)(l31 & ~3)) * 2u;
         if constexpr (!FULL) sok |= (oy < P.H && ox < P.W) ? (1u << (mt * 4 + g)) : 0u;
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
       const bool nqok = (n & ~3) < P.N;
       f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x2 a01 = {acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1]};
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
             s2 += a01; s2 += a23;
             q2 = a01 * a01 + q2; q2 = a23 * a23 + q2;
           } else {
-            const int oy = y0 + (wm * 2 + mt) * 2 + (g >> 1);
+            const int oy = y0 + (wm * MT + mt) * 2 + (g >> 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int p = k + 8 * g + 4 * lh;                   // MFMA row -> pixel (second row rotated, see aoff)
@@ -384,13 +401,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
     constexpr bool BIAS = decltype(Bc)::value;
     const int li = lane & 7;
     const bool upper = (li & 4) != 0;
-    unsigned sb16[2][2];
+    unsigned sb16[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int col = (li & 3) + 8 * (li >> 2) + 4 * lh;
-        const int oy = y0 + (wm * 2 + mt) * 2 + h;
+        const int oy = y0 + (wm * MT + mt) * 2 + h;
         const int ox = x0 + (h ? ((col - (HWd & 15)) & 15) : col);
         sb16[mt][h] = ((unsigned)((bb * P.H + oy) * P.W + ox) * (unsigned)dstride + (unsigned)(l31 & ~7)) * 2u;
       }
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
       const f32x2 bias2 = {biasv[nt], biasv[nt]};
       f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           unsigned E[4];
@@ -495,6 +512,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16_fast(BConvP P) {
 #endif
 }
 
+#ifndef FU_TILE_MODE_DEFAULT
+#define FU_TILE_MODE_DEFAULT 0
+#endif
+int g_bf16_tile_mode = FU_TILE_MODE_DEFAULT;   // 0 = heuristic, 1 = never the tall tile, 2 = tall wherever 64-channel tiles run
+
 bool conv3x3_bf16_fast_eligible(const BConvP& P) {
   const int64_t px = (int64_t)P.B * P.H * P.W;
   const int64_t lim = (int64_t)1 << 31;
@@ -506,9 +528,9 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P) {
   return true;
 }
 
-template <int NTW, int TAPS = 9>
+template <int NTW, int TAPS = 9, int MT = 2, int KCH = 32>
 static int launch_fast_cfg(BConvP& P, hipStream_t s) {
-  using Cfg = FCfg<NTW, TAPS>;
+  using Cfg = FCfg<NTW, TAPS, MT, KCH>;
   P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
   P.rcp_nPix = host_rcp(P.nPix); P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
@@ -516,14 +538,15 @@ static int launch_fast_cfg(BConvP& P, hipStream_t s) {
              P.nPix, P.nCo);
   static bool attr_set = false;
   if (!attr_set) {
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_fast<NTW, TAPS>),
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_fast<NTW, TAPS, MT, KCH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
   const ProfSlot ps = g_prof_slot;
   g_prof_slot = ProfSlot();
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW, TAPS>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW, TAPS, MT, KCH>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s,
+                     P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;
@@ -535,7 +558,16 @@ int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
   const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
   const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
   if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, s) : launch_fast_cfg<1, 1>(P, s);
+  // tall tile (16 x 32 pixels, 16-channel chunks).  Measured per layer against the square tile (bench shapes, one
+  // stream): 5-9 % faster where it still yields >= 2048 workgroups (the 256x256 layers; the 8-channel first conv 60 ->
+  // 46 us), within +-4 % at 1024, 10 % slower at <= 512 -- hence the threshold.
+  const int64_t t512 = (int64_t)P.B * ceil_div(P.H, 32) * ceil_div(P.W, 16);
+  const bool tall = g_bf16_tile_mode == 2 ? wide
+                                          : (g_bf16_tile_mode == 0 && wide && t512 * ceil_div(P.N, 64) >= 2048);
+  if (tall) return launch_fast_cfg<2, 9, 4, 16>(P, s);
   return wide ? launch_fast_cfg<2>(P, s) : launch_fast_cfg<1>(P, s);
 }
 
 }  // namespace fu
+
+extern "C" void fu_test_conv_tile_mode(int mode) { fu::g_bf16_tile_mode = mode; }

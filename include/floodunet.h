@@ -214,6 +214,9 @@ void fu_test_force_general_conv(int on);
 /* Testing hook: on != 0 runs the bf16 weight gradient of c_in > 64 on the lock-step kernel k_wgrad_bf16<4,8> instead of
  * the ping-pong kernel k_wgrad_bf16_pp (same accumulation order: the results are bit-identical).  Process-wide. */
 void fu_test_force_lockstep_wgrad(int on);
+/* Testing hook: workgroup tile of the aligned-shape bf16 conv kernel at 64 output channels: 0 = heuristic (default),
+ * 1 = never the tall 16x32-pixel tile, 2 = the tall tile wherever 64-channel tiles run.  Process-wide. */
+void fu_test_conv_tile_mode(int mode);
 /* Testing hook: on != 0 runs the late-fusion 1x1 convs (weights embedded as the centre tap of a 3x3) through all nine taps
  * instead of the 1-tap instantiation of the fast kernel; the other eight taps multiply exact zeros, so the results are
  * bit-identical.  Process-wide. */

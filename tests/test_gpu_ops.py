@@ -189,13 +189,16 @@ def nchw_bf(x):
     return x.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
-@pytest.fixture(params=["auto", "general"])
+@pytest.fixture(params=["auto", "general", "tall", "square"])
 def conv_path(request):
-    """bf16 forward/dgrad have an aligned-shape fast kernel and a general one: run every shape on both."""
+    """bf16 forward/dgrad have an aligned-shape fast kernel (16x16 and tall 16x32 workgroup tiles) and a general one:
+    run every shape on all of them."""
     lib = _lib.load()
     lib.fu_test_force_general_conv(1 if request.param == "general" else 0)
+    lib.fu_test_conv_tile_mode({"tall": 2, "square": 1}.get(request.param, 0))
     yield request.param
     lib.fu_test_force_general_conv(0)
+    lib.fu_test_conv_tile_mode(0)
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)
