@@ -711,10 +711,16 @@ int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
                                 s));
     FU_TRY(launch_center_from_w3(F.dw3, (int64_t)F.C * Ccat, G(c, F.p_w), s));
     ConvIn gin{F.gy, F.C, nullptr, nullptr, nullptr, 0, true};    // the flipped 3x3 of a centre tap is a centre tap
-    FU_TRY(launch_conv3x3(c->prec, gin, F.wd, nullptr, F.gcat, Ccat, nullptr, 0, nullptr, nullptr, B, H, W, s));
-    for (int e = 0; e < c->nE; ++e) {
-      Conv& v = c->blk[5 * e + l].c[1];
-      FU_TRY(launch_copy_channels(c->prec, F.gcat, Ccat, e * F.C, nullptr, nullptr, v.gy, v.cout, 0, F.C, npix, s));
+    if (c->nE == 2 && F.C % 64 == 0) {
+      // two encoders: the conv kernels' two destinations ARE the encoders' skip gradients (no concat gradient, no split)
+      FU_TRY(launch_conv3x3(c->prec, gin, F.wd, nullptr, c->blk[l].c[1].gy, F.C, c->blk[5 + l].c[1].gy, F.C, nullptr,
+                            nullptr, B, H, W, s));
+    } else {
+      FU_TRY(launch_conv3x3(c->prec, gin, F.wd, nullptr, F.gcat, Ccat, nullptr, 0, nullptr, nullptr, B, H, W, s));
+      for (int e = 0; e < c->nE; ++e) {
+        Conv& v = c->blk[5 * e + l].c[1];
+        FU_TRY(launch_copy_channels(c->prec, F.gcat, Ccat, e * F.C, nullptr, nullptr, v.gy, v.cout, 0, F.C, npix, s));
+      }
     }
   }
   return 0;
