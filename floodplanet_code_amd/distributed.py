@@ -8,8 +8,10 @@ on a single device, st_water_seg/fit.py:87-88, so the semantics are defined here
   * the only exchange is the gradient all-reduce over RCCL (torch.distributed backend "nccl").  Backward runs
     block by block (fu_backward_block); as soon as the blocks of a bucket are final, the bucket -- one contiguous
     slice of the flat gradient buffer -- is all-reduced asynchronously on RCCL's stream while the remaining
-    backward kernels keep the compute stream busy.  4 buckets for the full-width net (7.8 / 23.6 / 18.9 / 18.8 MB):
-    xGMI is point-to-point, so few large messages amortise the per-collective latency.
+    backward kernels keep the compute stream busy.  5 buckets for the full-width net at the default 16 MB cap
+    (7.8 / 23.6 / 18.9 / 14.2 / 4.6 MB; a block larger than the cap is a bucket by itself): xGMI is point-to-point, so
+    few large messages amortise the per-collective latency, and only the last 4.6 MB (down2, down1, inc) cannot overlap
+    with backward (with a 25 MB cap down3's 14.2 MB waited for the end of backward too).
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ _FORCE_BLOCKS = os.environ.get("FU_DP_FORCE_BLOCKS") == "1"
 _DIAG_MODE = None      # tools/dp_diag.py: override of the side-stream mode
 
 
-def plan_buckets(block_ranges: Sequence[Tuple[int, int]], cap_bytes: int = 25 << 20,
+def plan_buckets(block_ranges: Sequence[Tuple[int, int]], cap_bytes: int = 16 << 20,
                  elem_bytes: int = 4) -> List[Tuple[int, int, int]]:
     """Merge consecutive backward blocks into buckets.  block_ranges: (offset, numel) per block in backward
     order; consecutive blocks are adjacent in the flat buffer.  Returns (last_block_index, offset, numel)."""
@@ -53,7 +55,7 @@ class BucketedReducer:
     """Asynchronous bucketed sum all-reduce of a flat gradient buffer, driven by block completion."""
 
     def __init__(self, block_ranges: Sequence[Tuple[int, int]], world_size: int, group=None,
-                 cap_bytes: int = 25 << 20):
+                 cap_bytes: int = 16 << 20):
         self.world_size = world_size
         self.group = group
         self.buckets = plan_buckets(block_ranges, cap_bytes)
@@ -79,7 +81,7 @@ class DataParallelTrainer:
     """fwd + CE + block-wise bwd (+ overlapped all-reduce) + fused Adam on a HipUNet."""
 
     def __init__(self, net, lr: float, world_size: int = 1, rank: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None, cap_bytes: int = 25 << 20, exact: bool = False):
+                 group=None, cap_bytes: int = 16 << 20, exact: bool = False):
         """exact=False: DDP semantics (per-rank BN statistics and 1/N_valid, gradients averaged).
         exact=True: SyncBN statistics and a global N_valid (HipUNet.enable_exact_sync); the ranks together reproduce
         one device with world_size x the batch, gradients are summed (SURVEY.md 8(e) "exact mode")."""

@@ -29,11 +29,13 @@ def full_ranges():
 def test_bucket_plan_full_width_net():
     ranges, total = full_ranges()
     assert total == 17270403
-    b = plan_buckets(ranges, cap_bytes=25 << 20)
+    b = plan_buckets(ranges)                                   # default cap: 16 MB
     assert sum(n for _, _, n in b) == total
     assert [last for last, _, _ in b] == sorted(last for last, _, _ in b)
-    assert all(n * 4 <= (25 << 20) for _, _, n in b)
-    assert len(b) == 4
+    sizes = [round(n * 4 / 1e6, 1) for _, _, n in b]
+    assert sizes == [7.8, 23.6, 18.9, 14.2, 4.6], sizes          # up1 / down4 exceed the cap: single-block buckets
+    assert [last for last, _, _ in b] == [3, 4, 5, 6, 9]
+    assert len(plan_buckets(ranges, cap_bytes=25 << 20)) == 4
     # contiguous cover without overlap
     covered = sorted((off, off + n) for _, off, n in b)
     assert covered[0][0] == 0 and covered[-1][1] == total
