@@ -378,7 +378,8 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.center_only = (in.center_only && !g_bf16_force_full_taps) ? 1 : 0;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
-  FU_REQUIRE(P.C0 <= 1024, "conv3x3_bf16: at most 1024 channels in source 0 (got %d)", P.C0);
+  FU_REQUIRE(P.a0 == nullptr || P.C0 <= 1024, "conv3x3_bf16: at most 1024 BN-activated channels in source 0 (got %d)",
+             P.C0);   // (the LDS table of BN coefficients; a plain source has no such limit)
   // tile choice (all tiles are 16x16 = 256 output pixels).  Measured on MI355X (profiles/): two 4-wave workgroups
   // per CU (256x64 tile, 80 KB LDS) overlap one group's LDS staging with the other's MFMA block and beat the
   // 8-wave 256x128 tile (higher FLOP/byte but lock-step phases) on every layer that yields >= 512 workgroups;

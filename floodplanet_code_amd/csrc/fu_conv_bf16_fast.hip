@@ -522,7 +522,7 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P) {
   const int64_t lim = (int64_t)1 << 31;
   if (P.src1 && (P.C0 % 32) != 0) return false;
   if (P.dst1 && (P.D0 % 32) != 0) return false;
-  if (P.C0 > 1024 || (P.C0 % 8) || (P.C1 % 8) || (P.N % 4)) return false;
+  if ((P.a0 != nullptr && P.C0 > 1024) || (P.C0 % 8) || (P.C1 % 8) || (P.N % 4)) return false;
   if (px * P.C0 * 2 >= lim || px * P.C1 * 2 >= lim || px * P.D0 * 2 >= lim || px * P.D1 * 2 >= lim) return false;
   if ((int64_t)9 * P.N * P.Cin * 2 >= lim) return false;
   return true;

@@ -194,3 +194,31 @@ def test_one_tap_fusion_kernel_is_bit_identical_to_the_nine_tap_run():
     assert torch.isfinite(outs[0][0]).all() and outs[0][1].abs().max() > 0
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_three_encoders_at_full_width_match_the_live_oracle(precision):
+    """3 x 512 = 1536 concatenated channels at the two deepest fusion levels (more than the 1024-entry BN table of the conv
+    kernels, which only BN-activated sources need)."""
+    in_ch = OrderedDict([("ms_image", 4), ("dem", 1), ("slope", 1)])
+    st = O.lf_make_state(in_ch, 3, 64, seed=3)
+    batch = O.make_batch(1, 4, 32, 32, seed=6, extra=("dem", "slope"))
+    st_o = {k: v.clone() for k, v in st.items()}
+    logits_o, loss_o, grads_o = O.lf_loss_and_grads(st_o, batch, in_ch, 0)
+    net = HipLateFusion(in_ch, 3, base_channels=64, precision=precision)
+    net.load_state_dict(st)
+    net = net.to(DEV).train()
+    x, tgt = fused_input(batch, net).to(DEV), batch["target"].to(DEV)
+    loss, logits = net.loss(x, tgt, 0, return_logits=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    d = (logits.detach().cpu() - logits_o).abs().max().item()
+    g = {n: p.grad.detach().cpu() for n, p in net.named_parameters()}
+    k = "concat_convs.4.weight"
+    if precision == "fp32":
+        assert d <= LOGIT_TOL and abs(loss.item() - loss_o.item()) <= 1e-5
+        assert rel(g[k], grads_o[k]) <= GRAD_TOL
+    else:
+        assert d <= 0.35 and abs(loss.item() - loss_o.item()) <= 0.03 and torch.isfinite(net.flat_grads()).all()
+        a, b = g[k].double().reshape(-1), grads_o[k].double().reshape(-1)
+        assert (a @ b / (a.norm() * b.norm())).item() >= 0.9
