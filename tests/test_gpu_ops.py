@@ -174,6 +174,7 @@ BF_SHAPES = [
     (2, 64, 32, 96, 48, 80, True),   # interior + border tiles, two sources (switch after 2 chunks), 64 + 32 channel tiles
     (1, 96, 0, 32, 16, 16, False),   # one tile, narrow (32-channel) workgroups
     (2, 128, 64, 64, 40, 24, True),  # second destination at a 64-channel boundary (dgrad: D0 = 128)
+    (4, 32, 0, 64, 208, 200, True),  # >= 512 64-channel tiles with ragged rows AND columns: the tall 16x32 tile's masked epilogue
 ]
 
 
