@@ -253,11 +253,18 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
       constexpr int tap = st / Cfg::KSTEPS, ks = st % Cfg::KSTEPS;    // tap = index inside sW
       constexpr int gtap = tap + Cfg::TAP0;                           // its position in the 3x3 window
       constexpr int toff = ((gtap / 3) * HWd + (gtap % 3)) * KCP + ks * 16;
+      if constexpr (MT == 4) {   // no prefetch buffer: the weight fragments first, so that the first MFMAs of the step
+#pragma unroll                   // wait for 3 of the 6 reads only (FU_TALL_B_FIRST)
+        for (int nt = 0; nt < NTW; ++nt)
+          bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
+      if constexpr (MT != 4) {
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-        bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+        for (int nt = 0; nt < NTW; ++nt)
+          bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+      }
     };
     static_for<0, FD>([&](auto Sc) { load_frags(Sc, std::integral_constant<int, decltype(Sc)::value % NB>{}); });
     static_for<0, Cfg::NSTEPS>([&](auto S) {
