@@ -10,7 +10,9 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfloodunet.so")
+# FU_LIB_PATH selects another build of the same sources (A/B timing of kernel variants, tools/ab_libs.sh); it must
+# export the full ABI of include/floodunet.h like the in-tree library.
+LIB_PATH = os.environ.get("FU_LIB_PATH") or os.path.join(_HERE, "libfloodunet.so")
 
 FU_OK, FU_ERR_INVALID, FU_ERR_HIP, FU_ERR_STATE, FU_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FU_F32, FU_BF16 = 0, 1

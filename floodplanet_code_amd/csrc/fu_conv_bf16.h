@@ -66,9 +66,5 @@ struct BConvP {
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
 bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
-// (experimental/fu_conv_bf16_pp.hip: persistent two-group ping-pong variant, not built: 8 % slower)
-int launch_conv3x3_bf16_pp(BConvP& P, hipStream_t s);
-// (csrc/experimental/ holds two measured-slower restructurings of the fast kernel, fu_conv_bf16_pipe.hip and
-//  fu_conv_bf16_pp.hip, with launchers launch_conv3x3_bf16_pipe / _pp of this same signature; they are not built)
 
 }  // namespace fu

@@ -4,6 +4,7 @@
 # tools/per_layer.py, then copy what is to be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 set -e
+mkdir -p gpurun_out
 python3 bench.py --steps 30 --warmup 5 > gpurun_out/bench_bf16.json 2> gpurun_out/bench_bf16.err
 tail -c 1600 gpurun_out/bench_bf16.json
 python3 bench.py --steps 10 --warmup 3 --dtype f32 --no-cpu-baseline > gpurun_out/bench_f32.json 2> gpurun_out/bench_f32.err
