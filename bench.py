@@ -5,13 +5,20 @@ A "step" = one pass of the hot path over one batch of synthetic tiles already re
 forward (train-mode BN) + CrossEntropy(ignore_index) + backward + [gradient all-reduce when N>1] + Adam.
 Workload at N=1: BASELINE.json configs[1] -- UNet depth-4, 8-band 256x256 tiles, batch 16 per GPU.
 
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (one fresh child
+process per GPU, RCCL over `torch.distributed`, rendezvous on 127.0.0.1) before anything touches the GPU, relays rank
+0's JSON line and exits non-zero if any rank fails; under `python -m torch.distributed.run` it is simply one rank.
+
 One JSON line on stdout (rank 0).  See DESIGN.md "Measurement" for the definitions of `roofline`
-(HIP events around every launch of the dominant kernel, live in the timed region) and `cpu_baseline`
-(the oracle's restatement of the reference's torch-CPU step, timed on this box's host cores).
+(HIP events around every launch of the dominant kernel, live in the timed region), `cpu_baseline`
+(the oracle's restatement of the reference's torch-CPU step, timed on this box's host cores) and `miou_vs_ref`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,12 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PRECISION = {"f32": "fp32", "bf16": "bf16", "f16": "fp16"}
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -32,20 +38,96 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--channels", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
-                    help="bf16 = BASELINE.json configs[1] (default); f32 = the 1e-4 parity mode")
+    ap.add_argument("--dtype", default=os.environ.get("FU_BENCH_DTYPE", "bf16"), choices=["f32", "bf16", "f16"],
+                    help="bf16 = BASELINE.json configs[1] (default); f16 = configs[3]'s mixed mode; f32 = the 1e-4 parity mode")
     ap.add_argument("--model", default="unet", choices=["unet", "lf"],
                     help="unet = the headline workload (ms_model / ef_model); lf = the late-fusion net (lf_model.py): "
                          "--channels image bands + --aux one-band auxiliary inputs, one encoder each")
     ap.add_argument("--aux", type=int, default=1, help="--model lf: number of one-band auxiliary inputs (dem, slope, ...)")
+    ap.add_argument("--path", default="cabi", choices=["cabi", "plugin"],
+                    help="cabi = DataParallelTrainer over the C ABI (fused fwd+CE, block-wise bwd, fused Adam); plugin = what "
+                         "a fit.py user runs: build_model('ms_model') -> configure_optimizers() -> opt.zero_grad(); "
+                         "training_step(); loss.backward(); opt.step() (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-miou", action="store_true", help="skip the small HIP-vs-oracle training comparison (miou_vs_ref)")
     ap.add_argument("--no-serial-pass", action="store_true",
                     help="skip the extra un-timed pass that measures the dominant kernel without the side stream")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=20)
-    return ap.parse_args()
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps-b16", type=int, default=3, help="steps of the batch-16 CPU sample (0 = skip)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous test of the multi-rank launcher on the CPU (gloo): every rank all-reduces its rank")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, started before this process makes any torch.cuda / HIP call
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start n children of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's stdout
+    (the JSON line) and every rank's stderr; return non-zero if any rank failed.  The parent never touches the GPU and
+    never re-execs itself."""
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("FU_BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True                 # one rank is gone (or the job hangs): the others would wait in a collective
+            time.sleep(1.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()              # the exact children started above, never a pattern
+            break
+        time.sleep(0.1)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad or failed:
+        sys.stderr.write(f"bench.py launcher: ranks failed (rank, exit code): {bad}\n")
+        return 1
+    return 0
+
+
+def launch_check_rank():
+    """--launch-check: the rank side of the launcher test.  gloo on the CPU, no GPU, no HIP library."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("FU_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "rank_sum": t.item(),
+                          "local_rank": int(os.environ["LOCAL_RANK"]), "master_addr": os.environ["MASTER_ADDR"]}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def host_cores():
     """CPU cores this process may actually use: cgroup quota if there is one, else the affinity mask, capped at
     the GPU box's per-GPU CPU share (16) so that torch does not oversubscribe a 256-thread host."""
@@ -71,43 +153,165 @@ def lf_in_channels(channels, aux):
     return OrderedDict([("ms_image", channels)] + [(k, 1) for k in AUX_NAMES[:aux]])
 
 
-def cpu_baseline(channels, size, cpu_batch, cpu_steps, model="unet", aux=1):
-    """The oracle (kind 'port': torch-CPU restatement of the reference step, pinned bit-exactly against the
-    reference in the dev container) on this box's host cores, bounded sample."""
+def _cpu_sample(channels, size, batch_size, steps, model, aux):
+    import torch
     from oracle import unet_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
     if model == "lf":
         in_ch = lf_in_channels(channels, aux)
         st = O.lf_make_state(in_ch, 3, 64, seed=0)
-        batch = O.make_batch(cpu_batch, channels, size, size, seed=1, extra=tuple(AUX_NAMES[:aux]))
+        batch = O.make_batch(batch_size, channels, size, size, seed=1, extra=tuple(AUX_NAMES[:aux]))
         step = lambda: O.lf_train_step(st, opt, batch, in_ch, 0, 1e-4)      # noqa: E731
     else:
         st = O.make_state(channels, 3, 64, True, seed=0, nontrivial_bn=False)
-        batch = O.make_batch(cpu_batch, channels, size, size, seed=1)
+        batch = O.make_batch(batch_size, channels, size, size, seed=1)
         step = lambda: O.train_step(st, opt, batch, 0, 1e-4)                # noqa: E731
     opt = O.new_adam_state(st)
     step()  # warm-up
     times = []
-    for _ in range(cpu_steps):
+    for _ in range(steps):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(cpu_batch / best, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{cpu_steps} steps of batch {cpu_batch} ({channels}ch {size}x{size}, fp32 torch-CPU "
-                      f"{torch.__version__}, {torch.get_num_threads()} threads), best step {best:.3f}s"}
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {"batch": batch_size, "steps": steps, "median_step_s": round(med, 4), "best_step_s": round(times[0], 4),
+            "tiles_per_s_median": round(batch_size / med, 4), "tiles_per_s_best": round(batch_size / times[0], 4)}
+
+
+def cpu_baseline(args):
+    """The oracle (kind 'port': torch-CPU restatement of the reference step, pinned bit-exactly against the reference in
+    the dev container) on this box's host cores, bounded samples at batch 2 (BASELINE configs[0] shape) and batch 16
+    (configs[1] shape), as BASELINE.md section 4 prescribes: warm-up + timed steps, median and best."""
+    import torch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    b2 = _cpu_sample(args.channels, args.size, args.cpu_batch, args.cpu_steps, args.model, args.aux)
+    out = {"value": b2["tiles_per_s_median"], "unit": "tiles/s", "cores": cores, "kind": "port",
+           "sample": f"median of {args.cpu_steps} steps of batch {args.cpu_batch} after 1 warm-up ({args.channels}ch "
+                     f"{args.size}x{args.size}, fp32 torch-CPU {torch.__version__}, {torch.get_num_threads()} threads): "
+                     f"median {b2['median_step_s']}s, best {b2['best_step_s']}s per step",
+           "best": b2["tiles_per_s_best"], "batch2": b2}
+    if args.cpu_steps_b16 > 0:
+        out["batch16"] = _cpu_sample(args.channels, args.size, 16, args.cpu_steps_b16, args.model, args.aux)
+    return out
+
+
+def csrc_sha():
+    """Hash of the kernel sources the loaded library was built from (profiles/*_pmc_*.json records the same hash)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "floodplanet_code_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(dtype, kernel, standard_workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this same command; counters cannot be read live).  Only valid for the binary they were
+    taken from: the newest profiles/r*_pmc_<dtype>.json whose `csrc_sha` equals the hash of the sources in this tree."""
+    import glob
+    import re
+    if not standard_workload:
+        return None, "traffic: PMC passes exist for the default workload only"
+    sha = csrc_sha()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{dtype}.json")),
+                   key=lambda p: int(re.search(r"r(\d+)_pmc", os.path.basename(p)).group(1)), reverse=True)
+    for p in cands:
+        try:
+            pm = json.load(open(p))
+        except Exception:
+            continue
+        if pm.get("csrc_sha") == sha and kernel in pm:
+            return pm[kernel]["hbm_bytes_per_launch"], f"{os.path.basename(p)} (csrc_sha {sha})"
+    return None, f"traffic: no PMC summary under profiles/ was taken from these kernel sources (csrc_sha {sha})"
+
+
+def miou_vs_ref(dev, dtype):
+    """`mIoU vs ref` half of BASELINE.json's metric, on a bounded workload: the HIP path (this run's dtype, and fp32) and
+    the oracle (the reference's arithmetic, torch-CPU) train from the same seeded state on the same seeded tiles for the
+    same number of Adam steps; micro Jaccard over argmax with ignore_index (water_seg_model.py:46-63) of the eval-mode
+    predictions on those tiles, and the gaps."""
+    import torch
+    from floodplanet_code_amd.metrics import SegmentationMetrics
+    from floodplanet_code_amd.unet import HipUNet
+    from oracle import unet_oracle as O
+    B, Cc, S, base, steps, lr, ii = 4, 8, 64, 16, 30, 1e-3, 0
+    st0 = O.make_state(Cc, 3, base, True, seed=5, nontrivial_bn=False)
+    batch = O.make_batch(B, Cc, S, S, seed=9)
+    # a learnable signal: band 0 carries the label (as fit.SyntheticTiles does)
+    batch["image"][:, 0] = 0.5 * batch["image"][:, 0] + 0.5 * (batch["target"] == 1).float()
+
+    def jac(pred, target):
+        return SegmentationMetrics(3, ignore_index=ii)(pred.cpu(), target.cpu())["MulticlassJaccardIndex"].item()
+
+    st = {k: v.clone() for k, v in st0.items()}
+    opt = O.new_adam_state(st)
+    for _ in range(steps):
+        O.train_step(st, opt, batch, ii, lr)
+    out = {"oracle_fp32": jac(O.eval_forward(st, batch).argmax(1), batch["target"])}
+    x, t = batch["image"].to(dev), batch["target"].to(dev)
+    for name in dict.fromkeys(["fp32", PRECISION[dtype]]):
+        net = HipUNet(Cc, 3, base_channels=base, precision=name)
+        net.load_state_dict(st0)
+        net.to(dev).train()
+        for step in range(1, steps + 1):
+            net.train_step(x, t, ii)
+            net.adam_step(lr, step)
+        net.eval()
+        with torch.no_grad():
+            out[f"hip_{name}"] = jac(net(x).argmax(1), t)
+    ref = out["oracle_fp32"]
+    return {"workload": f"{steps} Adam steps (lr {lr}) on {B} seeded {Cc}ch {S}x{S} tiles, base width {base}, "
+                        f"ignore_index {ii}; micro Jaccard of the eval-mode argmax on the same tiles",
+            "jaccard": {k: round(v, 4) for k, v in out.items()},
+            "gap_vs_ref": {k: round(v - ref, 4) for k, v in out.items() if k != "oracle_fp32"}}
+
+
+class _PluginStepper:
+    """The drop-in path as fit.py / Lightning's automatic optimisation drives it (fit.py:95-97):
+    opt.zero_grad(); loss = model.training_step(batch, i); loss.backward(); opt.step()."""
+
+    def __init__(self, args, dev, precision):
+        from floodplanet_code_amd.models import build_model
+        import torch
+        torch.manual_seed(0)
+        self.model = build_model("ms_model", {"ms_image": args.channels}, 3, 1e-4, log_image_iter=50, to_rgb_fcn=None,
+                                 ignore_index=0, optimizer_name="adam", precision=precision).to(dev)
+        self.opt = self.model.configure_optimizers()
+        self.net = self.model.model
+        self.i = 0
+
+    def step(self, x, target, ignore_index):
+        batch = {"image": x, "target": target}
+        self.opt.zero_grad()
+        loss = self.model.training_step(batch, self.i)
+        loss.backward()
+        self.opt.step()
+        self.i += 1
+        return loss.detach()
 
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.launch_check and world_env is not None:
+        return launch_check_rank()
+    if args.gpus > 1 and world_env is None:
+        # BEFORE any torch.cuda / HIP call: this process only starts the ranks and relays their output
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        raise SystemExit("--launch-check needs --gpus N > 1")
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    if args.path == "plugin" and world > 1:
+        raise SystemExit("--path plugin measures the single-device Lightning path (fit.py:87-88: devices=1)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     n_dev = torch.cuda.device_count()
@@ -115,6 +319,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FU_DIST_BACKEND", "nccl")   # "gloo" = rehearsal of the N>1 path on one GPU
@@ -128,17 +333,21 @@ def main():
     from floodplanet_code_amd.unet import HipUNet
     import ctypes as C
 
-    precision = "fp32" if args.dtype == "f32" else "bf16"
+    precision = PRECISION[args.dtype]
     if os.environ.get("FU_BENCH_GENERAL_CONV") == "1":   # A/B knob: general bf16 conv kernel instead of the fast one
         _lib.load().fu_test_force_general_conv(1)
     torch.manual_seed(0)
-    if args.model == "lf":
-        from floodplanet_code_amd.latefusion import HipLateFusion
-        net = HipLateFusion(lf_in_channels(args.channels, args.aux), 3, base_channels=64, precision=precision)
-        net = net.to(dev).train()
+    if args.path == "plugin":
+        trainer = _PluginStepper(args, dev, precision)
+        net = trainer.net
     else:
-        net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
-    trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank)
+        if args.model == "lf":
+            from floodplanet_code_amd.latefusion import HipLateFusion
+            net = HipLateFusion(lf_in_channels(args.channels, args.aux), 3, base_channels=64, precision=precision)
+            net = net.to(dev).train()
+        else:
+            net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
+        trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank)
 
     B, Cc, S = args.batch, args.channels, args.size
     g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -159,6 +368,8 @@ def main():
     if world > 1:   # communicator set-up + parameter broadcast outside the steps (also with --warmup 0)
         trainer._sync_initial_state(dev)
     for _ in range(args.warmup):
+        trainer.step(x, target, 0)
+    if net._ctx is None:      # --warmup 0: the context is created by the first forward; the event profiler needs one
         trainer.step(x, target, 0)
     lib = _lib.load()
     # HIP events around every conv / wgrad launch serialise the kernel boundaries (~2 us per pair: 6.39 -> 6.66 ms per
@@ -196,21 +407,15 @@ def main():
             best = {"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "flops": fl.value}
     peak = PEAK_TFLOPS[args.dtype]
     roof = None
-    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of this same command; counters cannot be read live): profiles/r1_pmc_<dtype>.json
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", f"r1_pmc_{args.dtype}.json")) as fh:
-            pm = json.load(fh)
-        if best and best["kernel"] in pm and B == 16 and S == 256 and Cc == 8 and args.model == "unet":
-            traffic = pm[best["kernel"]]["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    traffic, traffic_src = (None, None)
+    if best:
+        traffic, traffic_src = pmc_traffic(args.dtype, best["kernel"],
+                                           B == 16 and S == 256 and Cc == 8 and args.model == "unet")
     # The weight-gradient chain runs on a side stream, concurrently with the dgrad launches of the dominant kernel: their
     # event-timed durations in the timed region include that sharing.  A short extra pass with the side stream off
     # (fu_set_side_stream) gives the same kernel's un-shared rate as `achieved_serial` (not part of `value`).
     serial = None
-    if best and world == 1 and not args.no_serial_pass:
+    if best and world == 1 and not args.no_serial_pass and args.path == "cabi":
         _lib.check(lib.fu_set_side_stream(net._ctx, 0))
         trainer.step(x, target, 0)
         _lib.check(lib.fu_profile_enable(net._ctx, 1))
@@ -227,7 +432,7 @@ def main():
     if best:
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": best["kernel"], "achieved": round(achieved, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": best["launches"], "event_timed_steps": sampled,
                 "avg_launch_ms": round(best["ms"] / best["launches"], 4),
                 "avg_launch_gflop": round(best["flops"] / best["launches"] / 1e9, 3),
@@ -240,24 +445,33 @@ def main():
             roof["hbm_gbps"] = round(gbps, 1)
             roof["hbm_frac_of_8tbps"] = round(gbps / 8000.0, 4)
 
+    wl = (f"UNet depth-4 (17.27M params), {Cc}-band {S}x{S} tiles, batch {B}/GPU, fwd+CE(ignore_index=0)+bwd+Adam, "
+          f"train-mode BN" if args.model == "unet" else
+          f"LateFusion ({1 + args.aux} UNet encoders + 1x1 fusion + decoder, {net._total / 1e6:.2f}M params), {Cc}-band "
+          f"image + {args.aux} aux {S}x{S} tiles, batch {B}/GPU, fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN")
+    cfg = {"workload": wl, "global_batch": B * world, "parallelism": f"dp{world}",
+           "train_gflop_per_tile": round(train_fl / 1e9, 3),
+           "path": ("C ABI: DataParallelTrainer.step" if args.path == "cabi" else
+                    "plugin: build_model('ms_model').training_step + loss.backward() + configure_optimizers().step()")}
+    if world > 1:
+        cfg["backend"] = backend
+        cfg["backward_chain"] = {0: "serial (one stream)", 1: "side stream, join per block",
+                                 2: "side stream, join per all-reduce bucket"}[trainer._side_mode()]
     out = {
         "metric": (f"training tiles/sec ({S}x{S}x{Cc}ch UNet)" if args.model == "unet" else
                    f"training tiles/sec ({S}x{S}, {Cc}ch image + {args.aux} aux, late fusion)"),
         "value": round(value, 3), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"UNet depth-4 (17.27M params), {Cc}-band {S}x{S} tiles, batch {B}/GPU, "
-                                f"fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN" if args.model == "unet" else
-                                f"LateFusion ({1 + args.aux} UNet encoders + 1x1 fusion + decoder, "
-                                f"{net._total / 1e6:.2f}M params), {Cc}-band image + {args.aux} aux {S}x{S} tiles, "
-                                f"batch {B}/GPU, fwd+CE(ignore_index=0)+bwd+Adam, train-mode BN"),
-                   "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_tile": round(train_fl / 1e9, 3)},
+        "config": cfg,
         "loss": round(float(loss.item()), 6),
         "roofline": roof,
     }
     if rank == 0:
+        if world == 1 and not args.no_miou:
+            out["miou_vs_ref"] = miou_vs_ref(dev, args.dtype)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(Cc, S, args.cpu_batch, args.cpu_steps, args.model, args.aux)
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

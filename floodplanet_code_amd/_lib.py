@@ -47,6 +47,7 @@ _i = C.c_int
 _i64 = C.c_int64
 SYNC_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)   # fu_sync_hook
 _f = C.c_float
+_d = C.c_double
 
 # name -> (restype, argtypes).  Every symbol include/floodunet.h declares is listed here; the
 # CPU test-suite checks that the library exports each of them.
@@ -70,7 +71,9 @@ SIGNATURES = {
     "fu_num_blocks": (_i, [_p]),
     "fu_backward_block": (_i, [_p, _i, _p, _p]),
     "fu_block_param_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
-    "fu_adam_step": (_i, [_p, _f, _f, _f, _f, _i64, _f, _p]),
+    "fu_bind_adam_state": (_i, [_p, _p, _p]),
+    "fu_scale_loss_grad": (_i, [_p, _p, _p]),
+    "fu_adam_step": (_i, [_p, _d, _d, _d, _d, _i64, _d, _p]),
     "fu_adam_state": (_i, [_p, C.POINTER(_p), C.POINTER(_p)]),
     "fu_zero_grads": (_i, [_p, _p]),
     "fu_stitch_add": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

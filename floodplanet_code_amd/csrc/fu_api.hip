@@ -301,7 +301,7 @@ struct fu_ctx {
   float* loss_dev = nullptr;
   unsigned long long* conf_tmp = nullptr;
   int64_t* n_valid = nullptr;
-  float* adam_m = nullptr;
+  float* adam_m = nullptr;        // bound (caller-owned, fu_bind_adam_state): the moments outlive the context
   float* adam_v = nullptr;
   Profiler prof;
   std::vector<PackTable> pack_tabs;   // <= MAX_PACK layers per launch
@@ -545,8 +545,6 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->loss_dev, 256);
   A.want(&c->conf_tmp, 64 * sizeof(unsigned long long));
   A.want(&c->n_valid, 256);
-  A.want(&c->adam_m, c->total_params * sizeof(float));
-  A.want(&c->adam_v, c->total_params * sizeof(float));
   FU_TRY(A.commit());
   for (int i = 5 * c->nE; i < c->nb && f.bilinear; ++i) {
     Block& K = c->blk[i];
@@ -1012,6 +1010,11 @@ int fu_bind_buffers(fu_ctx* c, float* params, float* grads, float* running_mean,
   c->pack_tabs.clear();
   return FU_OK;
 }
+int fu_bind_adam_state(fu_ctx* c, float* exp_avg, float* exp_avg_sq) {
+  FU_REQUIRE(c && exp_avg && exp_avg_sq, "fu_bind_adam_state: null argument");
+  c->adam_m = exp_avg; c->adam_v = exp_avg_sq;
+  return FU_OK;
+}
 int fu_params_changed(fu_ctx* c) {
   FU_REQUIRE(c, "null context");
   c->packed_dirty = true;
@@ -1075,6 +1078,16 @@ int fu_loss_bce_dice(fu_ctx* c, const int64_t* target, int ignore_index, float d
   return FU_OK;
 }
 
+int fu_scale_loss_grad(fu_ctx* c, const float* scale_dev, fu_stream stream) {
+  FU_REQUIRE(c && scale_dev, "fu_scale_loss_grad: null argument");
+  if (!(c->last_batch > 0 && c->fwd_training && c->have_loss)) {
+    set_error("fu_scale_loss_grad: no loss gradient stored (training fu_forward + fu_loss_* first)");
+    return FU_ERR_STATE;
+  }
+  const int64_t n = (int64_t)c->last_batch * c->cfg.height * c->cfg.width * c->cfg.n_classes;
+  return launch_scale_by_device_scalar(c->dlogits, n, scale_dev, (hipStream_t)stream);
+}
+
 int fu_num_blocks(const fu_ctx* c) { return c ? num_backward_blocks(c) : 0; }
 
 int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stream) {
@@ -1133,10 +1146,14 @@ int fu_block_param_range(const fu_ctx* c, int block, int64_t* flat_offset, int64
   return FU_OK;
 }
 
-int fu_adam_step(fu_ctx* c, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+int fu_adam_step(fu_ctx* c, double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                  fu_stream stream) {
   FU_REQUIRE(c && c->P && c->G, "fu_adam_step: parameter / gradient buffers not bound");
   FU_REQUIRE(step >= 1, "fu_adam_step: step is 1-based");
+  if (!c->adam_m || !c->adam_v) {
+    set_error("fu_adam_step: no moment buffers bound (fu_bind_adam_state)");
+    return FU_ERR_STATE;
+  }
   FU_TRY(launch_adam(c->P, c->G, c->adam_m, c->adam_v, c->total_params, lr, beta1, beta2, eps, step, grad_scale,
                      (hipStream_t)stream));
   c->packed_dirty = true;

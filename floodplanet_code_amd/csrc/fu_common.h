@@ -301,7 +301,8 @@ int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t
                            hipStream_t s);
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                float eps, int64_t step, float grad_scale, hipStream_t s);
+int launch_scale_by_device_scalar(float* x, int64_t n, const float* scale_dev, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                double eps, int64_t step, double grad_scale, hipStream_t s);
 
 }  // namespace fu

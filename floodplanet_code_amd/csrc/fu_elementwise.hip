@@ -1563,29 +1563,50 @@ int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t
 // Adam (torch.optim.Adam single-tensor update order; water_seg_model.py:200)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, int64_t n, float w1, float beta2, float omb2, float inv_bc2_sqrt,
+                       float* __restrict__ v, int64_t n, float w1, float beta2, float omb2, float bc2_sqrt,
                        float eps, float neg_step, float gscale) {
+  // every operation rounds on its own, in ATen's order (no fma contraction): with identical inputs the update is the
+  // same float sequence as torch's CPU Adam (lerp_ / mul_ / addcmul_ / sqrt / div / add_ / addcdiv_)
+#pragma clang fp contract(off)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     float mi = m[i], vi = v[i];
-    mi = mi + w1 * (gi - mi);                 // exp_avg.lerp_(grad, 1-beta1)
-    vi = vi * beta2 + (omb2 * gi) * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-    p[i] = p[i] + neg_step * (mi / denom);    // param.addcdiv_(exp_avg, denom, value=-step_size)
+    const float dm = gi - mi;
+    mi = mi + w1 * dm;                        // exp_avg.lerp_(grad, 1-beta1)      (weight < 0.5 branch of ATen's lerp)
+    const float vb = vi * beta2;
+    const float og = omb2 * gi;
+    vi = vb + og * gi;                        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    const float num = neg_step * mi;
+    p[i] = p[i] + num / denom;                // param.addcdiv_(exp_avg, denom, value=-step_size): self + value * t1 / t2
     m[i] = mi;
     v[i] = vi;
   }
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                float eps, int64_t step, float grad_scale, hipStream_t s) {
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const double step_size = (double)lr / bc1;
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                double eps, int64_t step, double grad_scale, hipStream_t s) {
+  // scalars are formed in double as torch.optim.Adam forms them in Python, then rounded once to float (the cast ATen
+  // applies to a Python scalar operand of a float tensor op)
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const double step_size = lr / bc1;
   const double bc2_sqrt = sqrt(bc2);
-  const float inv_bc2_sqrt = 1.0f / (float)bc2_sqrt;
-  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - (double)beta1),
-                     beta2, (float)(1.0 - (double)beta2), inv_bc2_sqrt, eps, (float)(-step_size), grad_scale);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size),
+                     (float)grad_scale);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// x[i] *= *scale_dev (the upstream gradient of the loss, a device scalar: no host read)
+__global__ void k_scale_by_device_scalar(float* __restrict__ x, int64_t n, const float* __restrict__ scale_dev) {
+  const float sc = *scale_dev;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] *= sc;
+}
+int launch_scale_by_device_scalar(float* x, int64_t n, const float* scale_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_by_device_scalar, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, x, n, scale_dev);
   FU_LAUNCH_CHECK();
   return 0;
 }

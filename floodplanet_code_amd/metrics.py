@@ -7,7 +7,9 @@ confusion matrix (PARITY UNPINNED -- no in-repo test or fixture of the reference
   * pixels whose target == ignore_index are dropped,
   * F1 / Accuracy (stat-scores based, micro):  tp = #correct, fp = fn = N - tp,
   * Jaccard (confusion-matrix based, micro): sum(diag) / (sum(union) - union[ignore_index])  when
-    0 <= ignore_index < n_classes  (torchmetrics' _jaccard_index_reduce).
+    0 <= ignore_index < n_classes  (torchmetrics' _jaccard_index_reduce).  A valid pixel PREDICTED as the ignore
+    class therefore still counts against its target class (row), but the ignore class's own union is left out.
+This is the single definition used by the product and restated by the oracle (oracle/unet_oracle.py).
 The HIP loss kernel emits the confusion counts fused with the cross entropy; ``update_from_counts`` feeds
 them in without touching the logits again.
 """
@@ -25,6 +27,8 @@ class SegmentationMetrics:
         self.num_classes = num_classes
         self.ignore_index = ignore_index
         self.prefix = prefix
+        # the running confusion matrix lives wherever the counts arrive (the GPU for the fused loss kernel's counters):
+        # nothing here reads a value back to the host; .item() / float() on a logged metric is the only sync point
         self._total = torch.zeros(num_classes, num_classes, dtype=torch.int64)
 
     def clone(self, prefix: str = "") -> "SegmentationMetrics":
@@ -42,34 +46,47 @@ class SegmentationMetrics:
         return torch.bincount(idx, minlength=n * n).view(n, n).to("cpu")
 
     def _reduce(self, m: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Micro reductions from a confusion matrix M[target, pred] whose ignored-target pixels were dropped.  Written
+        with tensor ops only (no host branch on a value), so that device-resident counts never force a sync.
+        THE definition of this repo (oracle/unet_oracle.py:metrics_from_counts restates the same rule; the test-suite
+        checks the two agree, also with predictions in the ignore class): torchmetrics'
+        `_jaccard_index_reduce(confmat, average="micro", ignore_index)` -- num = sum(diag), denom = sum(union) minus
+        union[ignore_index] when 0 <= ignore_index < num_classes, union = rows + cols - diag -- and its stat-scores
+        micro F1 / Accuracy (tp = #correct, fp = fn = N - tp)."""
         m = m.double()
         tp = m.diag().sum()
         tot = m.sum()
         fp = fn = tot - tp
-        zero = torch.zeros((), dtype=torch.float64)
-        f1 = 2 * tp / (2 * tp + fp + fn) if tot > 0 else zero
-        acc = tp / tot if tot > 0 else zero
+        one = torch.ones((), dtype=torch.float64, device=m.device)
+        f1 = torch.where(tot > 0, 2 * tp / torch.where(tot > 0, 2 * tp + fp + fn, one), 0 * one)
+        acc = torch.where(tot > 0, tp / torch.where(tot > 0, tot, one), 0 * one)
         union = m.sum(0) + m.sum(1) - m.diag()
         denom = union.sum()
         if self.ignore_index is not None and 0 <= self.ignore_index < self.num_classes:
             denom = denom - union[self.ignore_index]
-        jac = tp / denom if denom > 0 else zero
+        jac = torch.where(denom > 0, tp / torch.where(denom > 0, denom, one), 0 * one)
         p = self.prefix
         return {f"{p}MulticlassF1Score": f1.float(), f"{p}MulticlassJaccardIndex": jac.float(),
                 f"{p}MulticlassAccuracy": acc.float()}
 
     # -- torchmetrics-like protocol -----------------------------------------------------------------
+    def _accumulate(self, c: torch.Tensor) -> None:
+        if self._total.device != c.device:
+            self._total = self._total.to(c.device)
+        self._total += c
+
     def update(self, pred: torch.Tensor, target: torch.Tensor) -> None:
-        self._total += self._counts(pred, target)
+        self._accumulate(self._counts(pred, target))
 
     def update_from_counts(self, counts: torch.Tensor) -> Dict[str, torch.Tensor]:
-        c = counts.detach().to("cpu").view(self.num_classes, self.num_classes)
-        self._total += c
+        """counts: [n*n] or [n, n] int64 confusion counts of one batch (device-resident: they stay there)."""
+        c = counts.detach().view(self.num_classes, self.num_classes)
+        self._accumulate(c)
         return self._reduce(c)
 
     def __call__(self, pred: torch.Tensor, target: torch.Tensor) -> Dict[str, torch.Tensor]:
         c = self._counts(pred, target)
-        self._total += c
+        self._accumulate(c)
         return self._reduce(c)
 
     def compute(self) -> Dict[str, torch.Tensor]:

@@ -20,7 +20,7 @@ import torch.optim as optim
 
 from ..lightning_compat import LightningModule
 from ..metrics import SegmentationMetrics
-from ..unet import HipUNet
+from ..unet import HipAdam, HipUNet
 
 
 class WaterSegmentationModel(LightningModule):
@@ -79,9 +79,13 @@ class WaterSegmentationModel(LightningModule):
     def _set_model_to_eval(self):
         self.model.eval()
 
-    def _fused_loss(self, batch):
+    def _fused_loss(self, batch, want_logits=False):
+        """forward + CE(ignore_index) + NaN guard + argmax + confusion counts in the fused kernels.  The fp32 NCHW logits
+        are only written when someone needs them: training_step's image logging is disabled in the reference
+        (`if False:`, water_seg_model.py:116), so the training path never does; the counts stay on the device."""
         images = self._gather_input(batch)
-        loss, output = self.model.loss(images, batch['target'], self._loss_ignore, return_logits=True)
+        out = self.model.loss(images, batch['target'], self._loss_ignore, return_logits=want_logits)
+        loss, output = out if want_logits else (out, None)
         counts = self.model.pop_confusion()
         return loss, output, counts
 
@@ -111,7 +115,14 @@ class WaterSegmentationModel(LightningModule):
 
     def configure_optimizers(self):
         if self.optimizer_name == 'adam':
-            optimizer = optim.Adam(self.parameters(), lr=self.lr)
+            # optim.Adam(self.parameters(), lr=self.lr) (water_seg_model.py:200) as ONE fused kernel launch on the
+            # network's flat buffers; same hyper-parameters, param_groups and state_dict layout (unet.HipAdam).
+            # FU_TORCH_ADAM=1 keeps torch's own optimiser (it works on the same parameters).
+            import os
+            if os.environ.get("FU_TORCH_ADAM") == "1":
+                optimizer = optim.Adam(self.parameters(), lr=self.lr)
+            else:
+                optimizer = HipAdam(self.model, lr=self.lr)
         else:
             raise NotImplementedError(f'No implementation for optimizer of name: {self.optimizer_name}')
         return optimizer

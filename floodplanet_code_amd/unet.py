@@ -135,6 +135,11 @@ class HipUNet(nn.Module):
         self._flat: Optional[torch.Tensor] = None
         self._flat_grad: Optional[torch.Tensor] = None
         self._flat_rm = self._flat_rv = self._flat_nbt = None
+        # Adam moments (torch.optim.Adam's exp_avg / exp_avg_sq) as flat caller-owned buffers: bound into every context
+        # (fu_bind_adam_state), so they survive context re-creation (another tile size, a larger batch, .to(device))
+        self._flat_m: Optional[torch.Tensor] = None
+        self._flat_v: Optional[torch.Tensor] = None
+        self._generation = 0          # counts training forwards: an autograd node may only backward the latest one
         self._flat_valid = False
         self._ctx = None
         self._ctx_key = None
@@ -184,6 +189,14 @@ class HipUNet(nn.Module):
                 m.num_batches_tracked = nbt[i]
             self._flat, self._flat_rm, self._flat_rv, self._flat_nbt = flat, rm, rv, nbt
             self._flat_grad = torch.zeros(self._total, dtype=torch.float32, device=device)
+            for p_ in (p for _, p, _, _ in self._table):
+                p_.grad = None          # (a .grad that aliased the previous flat gradient buffer would go stale)
+            if self._flat_m is not None and self._flat_m.numel() == self._total:
+                self._flat_m = self._flat_m.to(device)      # the optimiser state moves with the module, never resets
+                self._flat_v = self._flat_v.to(device)
+            else:
+                self._flat_m = torch.zeros(self._total, dtype=torch.float32, device=device)
+                self._flat_v = torch.zeros(self._total, dtype=torch.float32, device=device)
         self._flat_valid = True
         self._destroy_ctx()
 
@@ -196,6 +209,15 @@ class HipUNet(nn.Module):
     def grad_views(self) -> List[torch.Tensor]:
         g = self._flat_grad
         return [g[off:off + n].view(p.shape) for _, p, off, n in self._table]
+
+    def adam_state(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(exp_avg, exp_avg_sq) flat fp32 buffers in parameter order (torch.optim.Adam's state, for checkpoints)."""
+        return self._flat_m, self._flat_v
+
+    def reset_adam_state(self):
+        if self._flat_m is not None:
+            self._flat_m.zero_()
+            self._flat_v.zero_()
 
     def attach_grads(self):
         """Point every parameter's .grad at its slice of the flat gradient buffer."""
@@ -236,6 +258,7 @@ class HipUNet(nn.Module):
         self._verify_table()
         check(lib.fu_bind_buffers(h, ptr(self._flat), ptr(self._flat_grad), ptr(self._flat_rm), ptr(self._flat_rv),
                                   ptr(self._flat_nbt)))
+        check(lib.fu_bind_adam_state(h, ptr(self._flat_m), ptr(self._flat_v)))
         self._eval_dirty = True
         self._install_exact_sync(device)
         return h
@@ -308,6 +331,8 @@ class HipUNet(nn.Module):
             self._eval_dirty = training  # a training step is followed by an optimiser update
         logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
         check(lib.fu_forward(ctx, ptr(x), B, int(training), ptr(logits), self._stream(x.device)))
+        if training:
+            self._generation += 1
         return logits
 
     def _loss_raw(self, target: torch.Tensor, ignore_index: int, device, kind: str = "ce",
@@ -373,7 +398,9 @@ class HipUNet(nn.Module):
     def adam_step(self, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
         """Native fused Adam on the flat buffers (torch.optim.Adam semantics, water_seg_model.py:200)."""
         dev = self._flat.device
-        check(_lib.load().fu_adam_step(self._ctx, lr, betas[0], betas[1], eps, step, grad_scale, self._stream(dev)))
+        check(_lib.load().fu_adam_step(self._ctx, float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                                       float(grad_scale), self._stream(dev)))
+        self._eval_dirty = True
 
     def flops_per_tile(self) -> Tuple[float, float]:
         f, t = C.c_double(), C.c_double()
@@ -391,6 +418,27 @@ class HipUNet(nn.Module):
         return out
 
 
+def _check_generation(ctx):
+    m = ctx.module
+    if ctx.generation != m._generation:
+        raise RuntimeError(
+            "HipUNet: backward() of a forward pass that is no longer the latest training forward of this module. The "
+            "saved activations live in the module's single device context (one forward in flight): call backward() "
+            "before the next training forward.")
+
+
+def _return_param_grads(m: "HipUNet"):
+    """Gradients of the HIP backward as autograd results.  Fast path (every p.grad is None, i.e. right after
+    optimizer.zero_grad(set_to_none=True), what Lightning and torch >= 2.0 do): point p.grad at the parameter's slice of
+    the flat gradient buffer the kernels have just written and hand autograd nothing to accumulate -- no 74 clones, no 74
+    accumulations, and HipAdam finds the gradients where fu_adam_step reads them.  Otherwise (a gradient is already
+    there: accumulation over several backward calls) return copies and let autograd add them."""
+    if all(p.grad is None for _, p, _, _ in m._table):
+        m.attach_grads()
+        return (None,) * len(m._table)
+    return tuple(g.clone() for g in m.grad_views())
+
+
 class _UNetFn(torch.autograd.Function):
     """logits = f(x; params): forward through fu_forward, backward through fu_backward(dlogits)."""
 
@@ -398,13 +446,16 @@ class _UNetFn(torch.autograd.Function):
     def forward(ctx, module: HipUNet, x, *params):
         ctx.module = module
         ctx.device = x.device
-        return module._forward_raw(x, True)
+        out = module._forward_raw(x, True)
+        ctx.generation = module._generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         m = ctx.module
+        _check_generation(ctx)
         m._backward_raw(dlogits.contiguous().float(), ctx.device)
-        return (None, None) + tuple(g.clone() for g in m.grad_views())
+        return (None, None) + _return_param_grads(m)
 
 
 class _UNetLossFn(torch.autograd.Function):
@@ -415,6 +466,7 @@ class _UNetLossFn(torch.autograd.Function):
         ctx.module = module
         ctx.device = x.device
         logits = module._forward_raw(x, True, want_logits=want_logits)
+        ctx.generation = module._generation
         loss = module._loss_raw(target, ignore_index, x.device, kind, dice_weight)
         if logits is None:
             logits = torch.empty(0, device=x.device)
@@ -424,6 +476,68 @@ class _UNetLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dlogits):
         m = ctx.module
+        _check_generation(ctx)
+        # the upstream gradient of the loss (ones for a plain loss.backward()) scales dL/dlogits once, on the device
+        dl = dloss.detach().reshape(()).to(device=ctx.device, dtype=torch.float32)
+        check(_lib.load().fu_scale_loss_grad(m._ctx, ptr(dl), m._stream(ctx.device)))
         m._backward_raw(None, ctx.device)
-        grads = tuple(g * dloss for g in m.grad_views())
-        return (None, None, None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + _return_param_grads(m)
+
+
+class HipAdam(torch.optim.Adam):
+    """A torch.optim.Adam (isinstance holds; same param_groups / defaults) (water_seg_model.py:198-205: lr, default betas / eps, no weight decay, no amsgrad) whose
+    step() is ONE launch of libfloodunet's fused Adam kernel on the module's flat parameter / gradient / moment
+    buffers (fu_adam_step).  param_groups[0] carries lr / betas / eps as torch's Adam does (LR schedulers work);
+    state_dict() holds {step, exp_avg, exp_avg_sq} per parameter like torch.optim.Adam's, the moments being views of the
+    module's flat buffers."""
+
+    def __init__(self, net: HipUNet, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        if not isinstance(net, HipUNet):
+            raise TypeError("HipAdam drives a HipUNet's flat buffers")
+        super().__init__([p for _, p, _, _ in net._table], lr=lr, betas=betas, eps=eps)
+        self._net = net
+        self._step = 0
+
+    def _views(self):
+        net = self._net
+        return [(p, net._flat_m[off:off + n].view(p.shape), net._flat_v[off:off + n].view(p.shape))
+                for _, p, off, n in net._table]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        net = self._net
+        if net._ctx is None:
+            raise RuntimeError("HipAdam.step() before any forward / backward of the module")
+        grads = net.grad_views()
+        if any(p.grad is None for _, p, _, _ in net._table):
+            raise RuntimeError("HipAdam.step(): a parameter has no gradient (the fused kernel updates all of them)")
+        # gradients that autograd accumulated outside the flat buffer (the slow path of _return_param_grads) come home
+        if net._table[0][1].grad.data_ptr() != grads[0].data_ptr():
+            torch._foreach_copy_(grads, [p.grad for _, p, _, _ in net._table])
+        g = self.param_groups[0]
+        self._step += 1
+        net.adam_step(g["lr"], self._step, g["betas"], g["eps"])
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._net._flat_m is not None:
+            sd["state"] = {i: {"step": torch.tensor(float(self._step)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+                           for i, (_, m, v) in enumerate(self._views())}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        st = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        if st:
+            if self._net._flat_m is None:
+                raise RuntimeError("HipAdam.load_state_dict(): move the module to its device first")
+            for i, (_, m, v) in enumerate(self._views()):
+                e = st[i] if i in st else st[str(i)]
+                m.copy_(e["exp_avg"])
+                v.copy_(e["exp_avg_sq"])
+                self._step = int(e["step"])

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FU_ABI_VERSION 2
+#define FU_ABI_VERSION 3
 #define FU_MAX_ENCODERS 6
 
 typedef struct fu_ctx fu_ctx;
@@ -142,6 +142,10 @@ int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
  * (default) as described; mode 2: fu_backward_block does not join -- the caller calls fu_backward_join(stream) before
  * it consumes gradients on `stream` (e.g. once per all-reduce bucket instead of once per block). */
 int fu_set_side_stream(fu_ctx* ctx, int mode);
+/* Multiply the stored loss gradient (dL/dlogits of the last fu_loss_* call) by the device scalar *scale_dev: the
+ * upstream gradient autograd hands to `loss.backward()` (fit.py:95-97), applied once to the logits gradient instead of
+ * to every parameter gradient, without a host read. */
+int fu_scale_loss_grad(fu_ctx* ctx, const float* scale_dev, fu_stream stream);
 int fu_backward_join(fu_ctx* ctx, fu_stream stream);
 
 /* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
@@ -150,11 +154,18 @@ int fu_num_blocks(const fu_ctx* ctx);
 int fu_backward_block(fu_ctx* ctx, int block, const float* dlogits, fu_stream stream);
 int fu_block_param_range(const fu_ctx* ctx, int block, int64_t* flat_offset, int64_t* numel);
 
-/* torch.optim.Adam semantics on the bound flat buffers (m, v owned by the context).
- * step is 1-based.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
-int fu_adam_step(fu_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+/* torch.optim.Adam semantics (water_seg_model.py:198-205) on the bound flat buffers.  The moments are CALLER-owned
+ * flat fp32 device buffers [fu_total_param_elems] in parameter order, zero-initialised by the caller (the state of
+ * torch.optim.Adam: exp_avg, exp_avg_sq); they outlive the context, so re-creating a context for another tile size or
+ * a larger batch does not reset the optimiser (ABI 2 kept them inside the context).  fu_adam_step without bound moments
+ * returns FU_ERR_STATE.  step is 1-based.  grad_scale multiplies the gradient first (1/world_size after a sum
+ * all-reduce).  The scalars are doubles, formed and rounded to float exactly as torch.optim.Adam forms its Python
+ * scalars; every operation of the update rounds on its own in ATen's order, so that with identical inputs the result
+ * is torch's. */
+int fu_bind_adam_state(fu_ctx* ctx, float* exp_avg, float* exp_avg_sq);
+int fu_adam_step(fu_ctx* ctx, double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                  fu_stream stream);
-int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* device pointers, for checkpoints */
+int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* the bound pointers (NULL when none) */
 int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
 
 /* ---- exact data-parallel mode (SyncBN statistics + global N_valid) ----------------

@@ -303,17 +303,30 @@ def confusion_counts(pred: torch.Tensor, target: torch.Tensor, n_classes: int,
     return m.reshape(n_classes, n_classes)
 
 
-def metrics_from_counts(m: np.ndarray) -> Dict[str, float]:
-    """Micro-averaged multiclass F1 / Jaccard / Accuracy from a confusion matrix whose
-    ignored-target pixels were already dropped.  PARITY UNPINNED: torchmetrics (third
-    party, pinned 0.10.0 in environment.yml:188, code needs >=0.11) is absent here; the
-    formulas are its documented micro reductions: tp = trace, fp = fn = total - tp."""
+def metrics_from_counts(m: np.ndarray, ignore_index: Optional[int] = None) -> Dict[str, float]:
+    """Micro-averaged multiclass F1 / Jaccard / Accuracy from a confusion matrix M[target, pred] whose
+    ignored-target pixels were already dropped (water_seg_model.py:46-63: MetricCollection of
+    F1Score / JaccardIndex / Accuracy, task="multiclass", average="micro", ignore_index).
+    PARITY UNPINNED: torchmetrics (third party, pinned 0.10.0 in environment.yml:188, code needs >=0.11) is
+    absent here; the formulas restate its reductions:
+      * stat-scores micro (F1, Accuracy): tp = trace, fp = fn = total - tp;
+      * `_jaccard_index_reduce(confmat, average="micro", ignore_index)`: num = sum(diag),
+        denom = sum(union) - union[ignore_index] when 0 <= ignore_index < n_classes, union = rows + cols - diag.
+        (Without predictions in the ignore class this equals tp / (tp + fp + fn).)
+    floodplanet_code_amd/metrics.py is the product's statement of the same rule; tests/test_models_api.py checks
+    that the two agree, including on a matrix with predictions in the ignore class."""
+    m = np.asarray(m, dtype=np.float64)
+    n = m.shape[0]
     tp = float(np.trace(m))
     tot = float(m.sum())
     fp = fn = tot - tp
     f1 = 2 * tp / (2 * tp + fp + fn) if tot > 0 else 0.0
-    jac = tp / (tp + fp + fn) if tot > 0 else 0.0
     acc = tp / tot if tot > 0 else 0.0
+    union = m.sum(0) + m.sum(1) - np.diag(m)
+    denom = float(union.sum())
+    if ignore_index is not None and 0 <= ignore_index < n:
+        denom -= float(union[ignore_index])
+    jac = tp / denom if denom > 0 else 0.0
     return {"MulticlassF1Score": f1, "MulticlassJaccardIndex": jac, "MulticlassAccuracy": acc}
 
 

@@ -235,14 +235,18 @@ def test_all_ignored_batch_gives_zero_loss_and_exact_zero_grads():
     assert not bool(torch.isnan(net.flat_grads()).any())
 
 
-def test_full_size_properties():
-    """BASELINE config 2 shape (B=16, 8ch, 256x256, full width): properties that need no CPU reference.
-    (a) determinism: two runs give bit-identical loss and gradients (fixed-order reductions, no atomics);
-    (b) batch linearity of CE: the loss of the batch equals the n_valid-weighted mean of per-half losses
-        only approximately under train-mode BN, so instead check eval-mode: logits of a sub-batch do not depend
-        on the rest of the batch; (c) gradient of an all-ignored batch is exactly zero."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_size_properties(prec):
+    """BASELINE configs[1] exactly as bench.py runs it (B=16, 8ch, 256x256, full width; bf16 = the benched dispatch: tall
+    conv tile, ping-pong wgrad, weight-gradient chain on the side stream): properties that need no CPU reference.
+    (a) determinism: two runs give bit-identical loss and gradients (fixed-order reductions, no atomics) -- with the side
+        stream ON in bf16;
+    (b) eval-mode logits of a sub-batch do not depend on the rest of the batch;
+    (c) the gradient of an all-ignored batch is exactly zero;
+    (d) bf16 only: the default dispatch equals the conservative one (square conv tiles, lock-step wgrad kernel, everything
+        on one stream) to bf16 rounding -- a wrong kernel variant on one layer is off by O(1) on that layer's gradient."""
     torch.manual_seed(0)
-    net = HipUNet(8, 3).to(DEV).train()
+    net = HipUNet(8, 3, precision=prec).to(DEV).train()
     batch = O.make_batch(16, 8, 256, 256, seed=11)
     x, t = batch["image"].to(DEV), batch["target"].to(DEV)
     l1 = net.train_step(x, t, 0).item()
@@ -253,6 +257,28 @@ def test_full_size_properties():
     assert l1 == l2 and torch.equal(g1, net.flat_grads())
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     assert not torch.equal(rm1, net.state_dict()["inc.double_conv.1.running_mean"])  # momentum update happened
+    if prec == "bf16":
+        from floodplanet_code_amd import _lib
+        lib = _lib.load()
+        try:
+            lib.fu_test_conv_tile_mode(1)
+            lib.fu_test_force_lockstep_wgrad(1)
+            _lib.check(lib.fu_set_side_stream(net._ctx, 0))
+            l3 = net.train_step(x, t, 0).item()
+            g3 = net.flat_grads().clone()
+            torch.cuda.synchronize()
+        finally:
+            lib.fu_test_conv_tile_mode(0)
+            lib.fu_test_force_lockstep_wgrad(0)
+            _lib.check(lib.fu_set_side_stream(net._ctx, 1))
+        assert abs(l3 - l1) <= 2e-3 * max(1.0, abs(l1)), (l1, l3)
+        worst = 0.0
+        for (k, p), gv1, gv3 in zip(net.named_parameters(), _views(net, g1), _views(net, g3)):
+            if is_dead_bias(k) or gv1.norm().item() < 1e-7:
+                continue
+            worst = max(worst, rel(gv3, gv1))
+            assert rel(gv3, gv1) <= 3e-2, (k, rel(gv3, gv1))     # tile shape changes the bf16 summation order only
+        assert worst > 0.0 or torch.equal(g1, g3)
     net.eval()
     with torch.no_grad():
         full = net(x)
@@ -261,6 +287,169 @@ def test_full_size_properties():
     net.train()
     lz = net.train_step(x, torch.zeros_like(t), 0).item()
     assert lz == 0.0 and float(net.flat_grads().abs().max()) == 0.0
+
+
+def _views(net, flat):
+    return [flat[off:off + n].view(p.shape) for _, p, off, n in net._table]
+
+
+def test_fused_adam_kernel_equals_torch_adam_on_fixture_gradients():
+    """fu_adam_step alone: load the reference fixture's step-1 gradients into the flat gradient buffer, run the fused
+    kernel twice, compare with the oracle's torch.optim.Adam restatement (pinned bit-exactly against torch.optim.Adam by
+    make_golden.py) element by element.  Every operation of k_adam rounds like ATen's, so the bound is 1e-7 relative
+    (observed: bit-identical); the 18 dead biases are INCLUDED here -- given the same gradient the update is the same."""
+    meta, z = load_golden("s_b2c4_32")
+    batch, st = case_inputs(meta)
+    lr = 1e-3
+    net = build(meta, st).train()
+    x, t = O.assemble_input(batch, False).to(DEV), batch["target"].to(DEV)
+    net.train_step(x, t, meta["resolved_ignore_index"])          # creates the context and binds the buffers
+    names = meta["names"]
+    grads = {}
+    for j, k in enumerate(names):
+        assert f"g1_{j}" in z.files
+        grads[k] = torch.from_numpy(z[f"g1_{j}"]).clone()
+    st_o = {k: v.clone() for k, v in st.items()}
+    opt = O.new_adam_state(st_o)
+    net.load_state_dict(st)                                       # undo nothing: parameters are still the initial ones
+    for step in (1, 2, 3):
+        for (k, p, off, n) in net._table:
+            net.flat_grads()[off:off + n].copy_(grads[k].reshape(-1).to(DEV))
+        net.adam_step(lr, step)
+        O.adam_update(st_o, grads, opt, lr)
+        grads = {k: g * 0.5 + 0.01 * st_o[k] for k, g in grads.items()}     # new gradients for the next step
+    torch.cuda.synchronize()
+    m, v = net.adam_state()
+    for (k, p, off, n) in net._table:
+        ref = st_o[k]
+        d = (p.detach().cpu() - ref).abs().max().item()
+        assert d <= 1e-7 * max(1.0, ref.abs().max().item()), (k, d)
+        assert torch.allclose(m[off:off + n].cpu().view(p.shape), opt["m"][k], rtol=1e-6, atol=1e-12), k
+        assert torch.allclose(v[off:off + n].cpu().view(p.shape), opt["v"][k], rtol=1e-6, atol=1e-20), k
+
+
+def test_adam_state_survives_context_recreation():
+    """The Adam moments are caller-owned flat buffers (ABI 3): a validation pass at another tile size, a larger batch or
+    a second .to(device) re-creates the device context but must not reset the optimiser.  Interrupted run == plain run."""
+    st = O.make_state(4, 3, 8, True, seed=2)
+    b_small = O.make_batch(2, 4, 32, 32, seed=3)
+    b_big = O.make_batch(4, 4, 32, 32, seed=4)
+    b_val = O.make_batch(1, 4, 48, 48, seed=5)
+
+    def run(interrupt):
+        net = HipUNet(4, 3, base_channels=8)
+        net.load_state_dict(st)
+        net.to(DEV).train()
+        step = 0
+        for it in range(3):
+            step += 1
+            net.train_step(b_small["image"].to(DEV), b_small["target"].to(DEV), 0)
+            net.adam_step(1e-3, step)
+        if interrupt:
+            net.eval()
+            with torch.no_grad():
+                net(b_val["image"].to(DEV))            # other H, W: the context is re-created
+            net.train()
+            net.to(DEV)                                 # no-op move: flat buffers are rebuilt
+        for it in range(2):
+            step += 1
+            net.train_step(b_big["image"].to(DEV), b_big["target"].to(DEV), 0)   # batch 4 > max_batch 2: re-created
+            net.adam_step(1e-3, step)
+        torch.cuda.synchronize()
+        return net.flat_parameters().clone(), net.adam_state()[0].clone()
+
+    p_plain, m_plain = run(False)
+    p_int, m_int = run(True)
+    assert m_plain.abs().max() > 0
+    assert torch.equal(m_plain, m_int)
+    assert torch.equal(p_plain, p_int)
+
+
+def test_backward_of_a_stale_forward_raises():
+    """One forward in flight per module (the saved activations live in the single device context): backward() of a graph
+    whose forward is not the latest training forward must raise instead of using the newer activations."""
+    st = O.make_state(4, 3, 8, True, seed=1)
+    batch = O.make_batch(2, 4, 32, 32, seed=2)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    net = HipUNet(4, 3, base_channels=8)
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    l1 = net.loss(x, t, 0)
+    l2 = net.loss(x * 0.5, t, 0)
+    with pytest.raises(RuntimeError, match="no longer the latest training forward"):
+        l1.backward()
+    l2.backward()
+    assert all(p.grad is not None for p in net.parameters())
+
+
+def test_plugin_path_uses_fused_adam_and_keeps_torch_semantics():
+    """configure_optimizers() returns HipAdam (one fused launch); the Lightning loop zero_grad / training_step / backward /
+    step gives the same parameters as torch.optim.Adam driven through the same loop (FU_TORCH_ADAM=1), the upstream
+    gradient of loss.backward() is honoured (loss * 3), accumulation over two backward calls adds up, and the optimiser
+    state round-trips through state_dict like torch.optim.Adam's."""
+    import os
+    batch = O.make_batch(2, 8, 64, 64, seed=3)
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+
+    def make(torch_adam):
+        torch.manual_seed(0)
+        m = build_model("ms_model", {"ms_image": 8}, 3, 1e-3, log_image_iter=50, to_rgb_fcn=None, ignore_index=0,
+                        base_channels=8).to(DEV)
+        os.environ["FU_TORCH_ADAM"] = "1" if torch_adam else "0"
+        try:
+            opt = m.configure_optimizers()
+        finally:
+            os.environ.pop("FU_TORCH_ADAM")
+        return m, opt
+
+    ma, oa = make(False)
+    mb, ob = make(True)
+    from floodplanet_code_amd.unet import HipAdam
+    assert isinstance(oa, HipAdam) and isinstance(ob, torch.optim.Adam)
+    for it in range(4):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            loss = m.training_step(batch, it)
+            loss.backward()
+            o.step()
+    torch.cuda.synchronize()
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        if not is_dead_bias(k.replace("model.", "", 1)):
+            assert (pa - pb).abs().max().item() <= 2e-6, k      # same gradients, same update rule (fused vs foreach order)
+    # upstream gradient and accumulation
+    oa.zero_grad()
+    (ma.training_step(batch, 0) * 3.0).backward()
+    g3 = [p.grad.clone() for p in ma.parameters()]
+    oa.zero_grad()
+    ma.training_step(batch, 0).backward()
+    g1 = [p.grad.clone() for p in ma.parameters()]
+    ma.training_step(batch, 0).backward()            # p.grad present -> accumulate
+    g2 = [p.grad.clone() for p in ma.parameters()]
+    for (k, _), a, b, c in zip(ma.named_parameters(), g1, g2, g3):
+        if is_dead_bias(k.replace("model.", "", 1)) or a.norm().item() < 1e-7:
+            continue
+        assert rel(b, 2 * a) <= 1e-5, k
+        assert rel(c, 3 * a) <= 1e-5, k
+    oa.step()                                         # gradients accumulated outside the flat buffer are copied home
+    sd = oa.state_dict()
+    assert len(sd["state"]) == len(list(ma.parameters())) and sd["param_groups"][0]["lr"] == 1e-3
+    m2, o2 = make(False)
+    m2.load_state_dict(ma.state_dict())
+    m2.training_step(batch, 0)                        # creates the flat buffers on the device
+    o2.load_state_dict(sd)
+    assert torch.equal(m2.model.adam_state()[0], ma.model.adam_state()[0])
+
+
+def test_miou_vs_ref_after_training_hip_and_oracle_side_by_side():
+    """`mIoU vs ref` (BASELINE.json metric): HIP fp32, HIP bf16 and the oracle (the reference's arithmetic)
+    train from the same state on the same seeded tiles; the micro Jaccard (argmax, ignore_index) of their eval-mode
+    predictions must agree: fp32 within 0.02, bf16 within 0.05 of the reference path."""
+    import bench
+    r = bench.miou_vs_ref(torch.device(DEV), "bf16")
+    j = r["jaccard"]
+    assert j["oracle_fp32"] > 0.5                    # the task was learnt at all
+    assert abs(r["gap_vs_ref"]["hip_fp32"]) <= 0.02, r
+    assert abs(r["gap_vs_ref"]["hip_bf16"]) <= 0.05, r
 
 
 # ---------------------------------------------------------------------------------------------------
