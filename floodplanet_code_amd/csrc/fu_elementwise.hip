@@ -1472,12 +1472,16 @@ __global__ void k_augment(const float* __restrict__ img, const int64_t* __restri
     int sx = ox, sy = oy;
     bool inside = true;
     if (f & 4) {
-      // torchvision F.rotate -> affine_grid + grid_sample(nearest, align_corners=False)
+      // torchvision F.rotate -> affine_grid + grid_sample(nearest, align_corners=False).  Index arithmetic: bit-exact
+      // with oracle/unet_oracle.py:augment -- the same fp32 operations in the same order, each rounded on its own (no
+      // fma contraction), cos / sin evaluated in double and rounded once to float, round-half-even.
+#pragma clang fp contract(off)
       const float th = angle[b] * 0.017453292519943295f;
-      const float cs = cosf(th), sn = sinf(th);
-      const float xc = (float)ox + 0.5f - 0.5f * (float)W, yc = (float)oy + 0.5f - 0.5f * (float)H;
-      const float xs = cs * xc - sn * yc + 0.5f * (float)W - 0.5f;
-      const float ys = sn * xc + cs * yc + 0.5f * (float)H - 0.5f;
+      const float cs = (float)cos((double)th), sn = (float)sin((double)th);
+      const float xc = ((float)ox + 0.5f) - 0.5f * (float)W, yc = ((float)oy + 0.5f) - 0.5f * (float)H;
+      const float px = cs * xc, qx = sn * yc, py = sn * xc, qy = cs * yc;
+      const float xs = ((px - qx) + 0.5f * (float)W) - 0.5f;
+      const float ys = ((py + qy) + 0.5f * (float)H) - 0.5f;
       sx = (int)nearbyintf(xs);
       sy = (int)nearbyintf(ys);
       inside = sx >= 0 && sx < W && sy >= 0 && sy < H;

@@ -331,6 +331,29 @@ def metrics_from_counts(m: np.ndarray, ignore_index: Optional[int] = None) -> Di
 
 
 # --------------------------------------------------------------------------- #
+# overlap-average stitching of tile predictions (utils/utils_image.py:363-494 as predict.py:296-334 drives it)
+# --------------------------------------------------------------------------- #
+def stitch_reference(logits: np.ndarray, boxes, H: int, W: int):
+    """ImageStitcher_v2.add_image / _combine_images restated: per crop i with box (h0, w0, hE, wE), softmax of the
+    [c, h, w] logits over c (scipy.special.softmax on the float32 'h w c' array, predict.py:298-301) is added into a
+    float32 canvas [H, W, c] at [h0:hE, w0:wE] (cut to dh x dw, utils_image.py:455-461), a float64 weight canvas counts
+    contributions, the result is canvas / (weight[:, :, None] + 1e-5) (float64) and nan_to_num (:472-489).
+    PINNED: tests/golden/stitch_*.npz were produced by the reference's own class (oracle/make_stitch_golden.py)."""
+    n, c = logits.shape[0], logits.shape[1]
+    canvas = np.zeros([H, W, c], dtype=np.float32)
+    weight = np.zeros([H, W], dtype="float")
+    for i, (h0, w0, hE, wE) in enumerate(boxes):
+        x = logits[i].transpose(1, 2, 0).astype(np.float32)
+        e = np.exp(x - x.max(axis=-1, keepdims=True))
+        pred = e / e.sum(axis=-1, keepdims=True)
+        dh, dw = hE - h0, wE - w0
+        canvas[h0:hE, w0:wE, :] += pred[:dh, :dw, :]
+        weight[h0:hE, w0:wE] += np.ones([dh, dw], dtype="float")
+    out = np.nan_to_num(canvas / (weight[:, :, None] + 1e-5))
+    return out, weight
+
+
+# --------------------------------------------------------------------------- #
 # augmentation (datasets/base_dataset.py:494-555 -> torchvision F.hflip / F.vflip / F.rotate)
 # --------------------------------------------------------------------------- #
 def augment(image: np.ndarray, target: np.ndarray, flag: int, angle_deg: float, target_fill: int = 0):
@@ -347,7 +370,10 @@ def augment(image: np.ndarray, target: np.ndarray, flag: int, angle_deg: float, 
     if flag & 4:
         C, H, W = img.shape
         th = np.float32(angle_deg) * np.float32(0.017453292519943295)
-        cs, sn = np.cos(th, dtype=np.float32), np.sin(th, dtype=np.float32)
+        # cos / sin in double, rounded once to float32 (the HIP kernel does the same: both sides then hold the correctly
+        # rounded float32 value, where float32 cos implementations differ in the last ulp); every later operation is
+        # one float32 rounding, left to right -- the kernel replays exactly this sequence (test: zero index mismatches)
+        cs, sn = np.float32(np.cos(np.float64(th))), np.float32(np.sin(np.float64(th)))
         oy, ox = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
         xc = ox + np.float32(0.5) - np.float32(0.5 * W)
         yc = oy + np.float32(0.5) - np.float32(0.5 * H)

@@ -2,6 +2,7 @@
 the same op as used in unet.py (F.conv2d / batch-norm+relu prologue / max_pool2d / bilinear upsample)."""
 import ctypes as C
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -331,6 +332,7 @@ def test_gpu_augmentation_matches_oracle_and_flip_identities():
     tgt = torch.randint(0, 3, (B, H, W), generator=g)
     flags = [0, 1, 2, 3, 4, 7]
     angles = [0.0, 0.0, 0.0, 0.0, 33.0, 211.5]
+    many = list(np.random.RandomState(0).uniform(0.0, 360.0, size=24)) + [45.0, 90.0, 180.0, 270.0, 359.999, 1e-3]
     out, tout = augment.apply(img.to(DEV), tgt.to(DEV), flags, angles, target_fill=0)
     torch.cuda.synchronize()
     out, tout = out.cpu(), tout.cpu()
@@ -341,7 +343,17 @@ def test_gpu_augmentation_matches_oracle_and_flip_identities():
     for b in (4, 5):
         ri, rt = O.augment(img[b].numpy(), tgt[b].numpy(), flags[b], angles[b], 0)
         mism = (out[b].numpy() != ri).any(0) | (tout[b].numpy() != rt)
-        assert mism.mean() < 2e-3     # cosf/sinf vs numpy may flip a rounding tie on a few pixels
+        assert mism.sum() == 0        # index work: bit-exact (same fp32 op order as the oracle, round-half-even)
+    # 30 more angles (uniform draws as sample_transforms makes them, plus the axis-aligned ones), odd and even sizes
+    for (hh, ww) in ((40, 56), (37, 45)):
+        im = torch.rand(len(many), 3, hh, ww, generator=g)
+        tg = torch.randint(0, 3, (len(many), hh, ww), generator=g)
+        fl = [4 + (i % 4) for i in range(len(many))]
+        o, to = augment.apply(im.to(DEV), tg.to(DEV), fl, many, target_fill=2)
+        torch.cuda.synchronize()
+        for b in range(len(many)):
+            ri, rt = O.augment(im[b].numpy(), tg[b].numpy(), fl[b], many[b], 2)
+            assert (o[b].cpu().numpy() != ri).sum() == 0 and (to[b].cpu().numpy() != rt).sum() == 0, (hh, ww, many[b])
     # a 90 degree rotation of a square tile is an exact rot90
     sq = torch.rand(1, 2, 32, 32, generator=g)
     o2, _ = augment.apply(sq.to(DEV), None, [4], [90.0])

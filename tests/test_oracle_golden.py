@@ -1,11 +1,14 @@
 """CPU: the oracle (oracle/unet_oracle.py) against the golden fixtures produced from the REAL reference by
 oracle/make_golden.py.  In the generating container the match is bit-exact; here a tight tolerance is used
 because another host CPU may pick other ATen/oneDNN code paths."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import case_inputs, golden_names, is_dead_bias, lf_case_inputs, load_golden
+from conftest import GOLDEN, case_inputs, golden_names, is_dead_bias, lf_case_inputs, load_golden
 from oracle import unet_oracle as O
 
 FAST = [n for n in golden_names() if n.startswith("s_")] + ["m_base8_64", "f_full_c8_32"]
@@ -96,3 +99,25 @@ def test_late_fusion_param_spec():
     assert keys[0] == "encoders.ms_image.inc.double_conv.0.weight" and keys[-1] == "concat_convs.4.bias"
     assert spec["concat_convs.3.weight"][0] == (512, 1536, 1, 1) and spec["concat_convs.4.weight"][0] == (512, 1536, 1, 1)
     assert "decoder.outc.conv.weight" in spec and "decoder.inc.double_conv.0.weight" not in spec
+
+
+@pytest.mark.parametrize("name", ["stitch_overlap_96x112", "stitch_partial_120x100"])
+def test_oracle_stitching_matches_the_reference_class(name):
+    """O.stitch_reference against canvases produced by the reference's own ImageStitcher_v2 (AST-extracted and run in the
+    build container by oracle/make_stitch_golden.py), incl. crops cut at the raster's edge."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    canvas, weight = O.stitch_reference(z["logits"], meta["boxes"], meta["H"], meta["W"])
+    np.testing.assert_array_equal(weight, z["weight"])
+    np.testing.assert_allclose(canvas, z["canvas"], rtol=0, atol=3e-7)     # scipy softmax vs exp/sum: last-ulp float32
+    assert canvas.dtype == z["canvas"].dtype == np.float64
+    # and the oracle's eval forward still produces the stored logits from the seeds alone
+    st = O.make_state(meta["C"], 3, meta["base"], True, seed=meta["param_seed"])
+    big = torch.from_numpy(O.hash_uniform(meta["C"] * meta["H"] * meta["W"], meta["data_seed"], 77)
+                           .astype(np.float32).reshape(meta["C"], meta["H"], meta["W"]))
+    S = meta["S"]
+    h0, w0, hE, wE = meta["boxes"][-1]
+    x = torch.zeros(1, meta["C"], S, S)
+    x[0, :, :hE - h0, :wE - w0] = big[:, h0:hE, w0:wE]
+    lg = O.eval_forward(st, {"image": x})
+    np.testing.assert_allclose(lg[0].numpy(), z["logits"][-1], rtol=0, atol=2e-5)
