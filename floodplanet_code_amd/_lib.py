@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FU_LIB_PATH") or os.path.join(_HERE, "libfloodunet.so")
 
 FU_OK, FU_ERR_INVALID, FU_ERR_HIP, FU_ERR_STATE, FU_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-FU_F32, FU_BF16 = 0, 1
-PRECISIONS = {"fp32": FU_F32, "f32": FU_F32, "float32": FU_F32, "bf16": FU_BF16, "bfloat16": FU_BF16}
+FU_F32, FU_BF16, FU_F16 = 0, 1, 2
+PRECISIONS = {"fp32": FU_F32, "f32": FU_F32, "float32": FU_F32, "bf16": FU_BF16, "bfloat16": FU_BF16,
+              "fp16": FU_F16, "f16": FU_F16, "float16": FU_F16, "half": FU_F16}
 
 
 class FuConfig(C.Structure):

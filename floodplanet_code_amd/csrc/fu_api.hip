@@ -24,19 +24,24 @@ namespace fu {
 
 // ---- precision dispatch -------------------------------------------------------------------------
 int conv3x3_num_stat_tiles(Prec p, int B, int H, int W) {
-  return p == PREC_F32 ? conv3x3_num_stat_tiles_f32(B, H, W) : conv3x3_num_stat_tiles_bf16(B, H, W);
+  return p == PREC_F32 ? conv3x3_num_stat_tiles_f32(B, H, W)
+                       : (p == PREC_BF16 ? conv3x3_num_stat_tiles_bf16(B, H, W) : conv3x3_num_stat_tiles_f16(B, H, W));
 }
 int launch_conv3x3(Prec p, const ConvIn& in, const void* wpk, const float* bias, void* dst0, int D0, void* dst1,
                    int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
   if (p == PREC_F32)
     return launch_conv3x3_f32(in, (const float*)wpk, bias, (float*)dst0, D0, (float*)dst1, D1, stats, n_stat_tiles, B,
                               H, W, s);
-  return launch_conv3x3_bf16(in, (const bf16_t*)wpk, bias, (bf16_t*)dst0, D0, (bf16_t*)dst1, D1, stats, n_stat_tiles,
-                             B, H, W, s);
+  if (p == PREC_BF16)
+    return launch_conv3x3_bf16(in, (const bf16_t*)wpk, bias, (bf16_t*)dst0, D0, (bf16_t*)dst1, D1, stats, n_stat_tiles,
+                               B, H, W, s);
+  return launch_conv3x3_f16(in, (const bf16_t*)wpk, bias, (bf16_t*)dst0, D0, (bf16_t*)dst1, D1, stats, n_stat_tiles, B,
+                            H, W, s);
 }
 int64_t conv3x3_wgrad_slab_elems(Prec p, int Cin, int Cout, int B, int H, int W) {
   return p == PREC_F32 ? conv3x3_wgrad_slab_elems_f32(Cin, Cout, B, H, W)
-                       : conv3x3_wgrad_slab_elems_bf16(Cin, Cout, B, H, W);
+                       : (p == PREC_BF16 ? conv3x3_wgrad_slab_elems_bf16(Cin, Cout, B, H, W)
+                                         : conv3x3_wgrad_slab_elems_f16(Cin, Cout, B, H, W));
 }
 int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, float* slab, float* dw_oihw,
                          int cin_real, const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
@@ -44,8 +49,11 @@ int launch_conv3x3_wgrad(Prec p, const ConvIn& in, const void* dy, int Cout, flo
   if (p == PREC_F32)
     return launch_conv3x3_wgrad_f32(in, (const float*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
                                     db, B, H, W, s);
-  return launch_conv3x3_wgrad_bf16(in, (const bf16_t*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
-                                   db, B, H, W, s);
+  if (p == PREC_BF16)
+    return launch_conv3x3_wgrad_bf16(in, (const bf16_t*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials,
+                                     db, B, H, W, s);
+  return launch_conv3x3_wgrad_f16(in, (const bf16_t*)dy, Cout, slab, dw_oihw, cin_real, db_partials, n_db_partials, db,
+                                  B, H, W, s);
 }
 int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout) {
   (void)p;
@@ -54,7 +62,8 @@ int64_t conv3x3_pack_elems(Prec p, int cin_pad, int Cout) {
 int launch_pack_conv3x3(Prec p, const float* w_oihw, int Cout, int cin_real, int cin_pad, void* wfwd, void* wdgrad,
                         hipStream_t s) {
   if (p == PREC_F32) return launch_pack_conv3x3_f32(w_oihw, Cout, cin_real, cin_pad, (float*)wfwd, (float*)wdgrad, s);
-  return launch_pack_conv3x3_bf16(w_oihw, Cout, cin_real, cin_pad, (bf16_t*)wfwd, (bf16_t*)wdgrad, s);
+  if (p == PREC_BF16) return launch_pack_conv3x3_bf16(w_oihw, Cout, cin_real, cin_pad, (bf16_t*)wfwd, (bf16_t*)wdgrad, s);
+  return launch_pack_conv3x3_f16(w_oihw, Cout, cin_real, cin_pad, (bf16_t*)wfwd, (bf16_t*)wdgrad, s);
 }
 
 }  // namespace fu
@@ -74,7 +83,10 @@ struct PackDesc {
 constexpr int MAX_PACK = 32;
 struct PackTable { PackDesc d[MAX_PACK]; int n; int64_t total; int tiles; };
 
-template <typename T, bool BF16_LAYOUT>
+// fp32 -> raw 16-bit storage of the context's element type
+template <bool HALF> __device__ __forceinline__ unsigned short cvt16(float v) { return HALF ? f2h(v) : f2bf(v); }
+
+template <typename T, bool BF16_LAYOUT, bool HALF = false>
 __global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tab.total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -100,8 +112,8 @@ __global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
     T* wf = (T*)D.wf;
     T* wd = (T*)D.wd;
     if (BF16_LAYOUT) {
-      wf[e] = (T)f2bf(v);
-      if (wd) wd[((int64_t)(8 - tap) * D.cin_pad + ci) * D.cout + co] = (T)f2bf(v);
+      wf[e] = (T)cvt16<HALF>(v);
+      if (wd) wd[((int64_t)(8 - tap) * D.cin_pad + ci) * D.cout + co] = (T)cvt16<HALF>(v);
     } else {
       ElemIO<T>::store1(wf + e, v);
       if (wd) ElemIO<T>::store1(wd + ((int64_t)(8 - tap) * D.cout + co) * D.cin_pad + ci, v);
@@ -113,7 +125,8 @@ __global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
 // 1152-byte runs, both packed layouts are written as 16-byte vectors along their fastest dimension (wf: c_in,
 // wd: c_out); the element-wise kernel above reads with a 36-byte stride and writes 2-byte values 2*cout bytes apart
 // (142 us per step for the 17M-parameter UNet, 8x its HBM time).  Needs cout % 8 == 0 and cin_pad % 8 == 0.
-__global__ __launch_bounds__(256) void k_pack_tiles_bf16(const float* __restrict__ params, PackTable tab) {
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_pack_tiles_16(const float* __restrict__ params, PackTable tab) {
   constexpr int PITCH = 34;
   __shared__ unsigned short sT[9][32][PITCH];
   int l = 0;
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256) void k_pack_tiles_bf16(const float* __restrict
     const int ci_l = r / 9, tap = r - ci_l * 9;
     const int co = co0 + co_l, ci = ci0 + ci_l;
     const float v = (co < D.cout && ci < D.cin_real) ? w[((size_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
-    sT[tap][co_l][ci_l] = f2bf(v);
+    sT[tap][co_l][ci_l] = cvt16<HALF>(v);
   }
   __syncthreads();
   bf16_t* wf = (bf16_t*)D.wf;
@@ -299,6 +312,7 @@ struct fu_ctx {
   float* ce_part = nullptr;
   float* hb_part = nullptr;
   float* loss_dev = nullptr;
+  float* loss_scale = nullptr;    // fp16 mode: {S, 1/S} of the running backward (fu_common.h, launch_loss_scale)
   unsigned long long* conf_tmp = nullptr;
   int64_t* n_valid = nullptr;
   float* adam_m = nullptr;        // bound (caller-owned, fu_bind_adam_state): the moments outlive the context
@@ -543,6 +557,7 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->ce_part, 2 * 1024 * sizeof(float));
   A.want(&c->hb_part, head_bwd_partial_elems(f.base_channels, f.n_classes) * sizeof(float));
   A.want(&c->loss_dev, 256);
+  A.want(&c->loss_scale, 256);
   A.want(&c->conf_tmp, 64 * sizeof(unsigned long long));
   A.want(&c->n_valid, 256);
   FU_TRY(A.commit());
@@ -605,10 +620,14 @@ int repack(fu_ctx* c, hipStream_t s) {
   for (const PackTable& t : c->pack_tabs) {
     if (c->prec == PREC_F32)
       hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t);
+    else if (t.tiles > 0 && c->prec == PREC_BF16)
+      hipLaunchKernelGGL(k_pack_tiles_16<false>, dim3(t.tiles), dim3(256), 0, s, c->P, t);
     else if (t.tiles > 0)
-      hipLaunchKernelGGL(k_pack_tiles_bf16, dim3(t.tiles), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL(k_pack_tiles_16<true>, dim3(t.tiles), dim3(256), 0, s, c->P, t);
+    else if (c->prec == PREC_BF16)
+      hipLaunchKernelGGL((k_pack_all<bf16_t, true, false>), dim3(grid), dim3(256), 0, s, c->P, t);
     else
-      hipLaunchKernelGGL((k_pack_all<bf16_t, true>), dim3(grid), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL((k_pack_all<bf16_t, true, true>), dim3(grid), dim3(256), 0, s, c->P, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
   }
@@ -851,6 +870,8 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
       FU_TRY(launch_dlogits_from_nchw(dlogits_ext, c->dlogits, f.n_classes, B, f.height, f.width, s));
     else
       FU_REQUIRE(c->have_loss, "fu_backward: no dlogits given and no fu_loss_* call since the last forward");
+    if (c->prec == PREC_F16)      // fp16 gradient maps: power-of-two loss scale from max|dL/dlogits| (UnscaleScope removes it)
+      FU_TRY(launch_loss_scale(c->dlogits, (int64_t)B * f.height * f.width * f.n_classes, c->ce_part, c->loss_scale, s));
     Conv& last = c->blk[c->nb - 1].c[1];
     FU_TRY(launch_head_bwd(c->prec, c->dlogits, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
                            (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s));
@@ -925,10 +946,11 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   FU_REQUIRE(b == 4 || b == 8 || b == 16 || b == 32 || b == 64, "base_channels must be 4, 8, 16, 32 or 64");
   FU_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
   FU_REQUIRE(cfg->height >= 16 && cfg->width >= 16, "tile must be at least 16x16");
-  FU_REQUIRE(cfg->precision == FU_F32 || cfg->precision == FU_BF16, "unknown precision %d", cfg->precision);
+  FU_REQUIRE(cfg->precision == FU_F32 || cfg->precision == FU_BF16 || cfg->precision == FU_F16, "unknown precision %d",
+             cfg->precision);
   FU_REQUIRE(cfg->bilinear || b == 64, "bilinear=0 exists only at base_channels 64 (the reference's UNetDecoder "
              "channel plan is inconsistent for bilinear=False, unet.py:176-183)");
-  FU_REQUIRE(cfg->precision == FU_F32 || b >= 8, "bf16 precision needs base_channels >= 8");
+  FU_REQUIRE(cfg->precision == FU_F32 || b >= 8, "bf16 / fp16 precision needs base_channels >= 8");
   FU_REQUIRE(cfg->n_encoders >= 0 && cfg->n_encoders <= FU_MAX_ENCODERS, "n_encoders must be 0..%d", FU_MAX_ENCODERS);
   if (cfg->n_encoders >= 1) {
     FU_REQUIRE(cfg->bilinear, "late fusion exists only with bilinear upsampling (lf_model.py:38)");
@@ -943,7 +965,7 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   fu_ctx* c = new (std::nothrow) fu_ctx();
   FU_REQUIRE(c, "out of host memory");
   c->cfg = *cfg;
-  c->prec = cfg->precision == FU_F32 ? PREC_F32 : PREC_BF16;
+  c->prec = cfg->precision == FU_F32 ? PREC_F32 : (cfg->precision == FU_BF16 ? PREC_BF16 : PREC_F16);
   c->esize = c->prec == PREC_F32 ? 4 : 2;
   int st = build_plan(c);
   if (st == 0) st = alloc_workspace(c);
@@ -1026,11 +1048,19 @@ struct SyncScope {   // makes the context's exact-sync descriptor visible to the
   explicit SyncScope(const fu_ctx* c, bool on) { fu::g_sync = (on && c && c->sync.hook) ? &c->sync : nullptr; }
   ~SyncScope() { fu::g_sync = nullptr; }
 };
+struct UnscaleScope {   // backward calls in fp16 mode: parameter gradients are written times 1 / loss scale
+  explicit UnscaleScope(const fu_ctx* c) { fu::g_grad_unscale = (c && c->prec == PREC_F16) ? c->loss_scale + 1 : nullptr; }
+  ~UnscaleScope() { fu::g_grad_unscale = nullptr; }
+};
 }  // namespace
 
 int fu_set_exact_sync(fu_ctx* c, fu_sync_hook hook, void* user, int world, void* exchange, int64_t exchange_bytes) {
   FU_REQUIRE(c, "null context");
   if (!hook || world <= 1) { c->sync = fu::SyncDesc(); return FU_OK; }
+  if (c->prec == PREC_F16) {   // every rank picks its own loss scale: the summed BN-backward statistics would mix scales
+    set_error("fu_set_exact_sync: the exact (SyncBN) mode is not available in fp16 precision; use bf16 or fp32");
+    return FU_ERR_UNSUPPORTED;
+  }
   FU_REQUIRE(exchange && exchange_bytes >= fu_exact_sync_bytes(c), "fu_set_exact_sync: exchange buffer of at least %lld bytes needed",
              (long long)fu_exact_sync_bytes(c));
   c->sync.hook = hook; c->sync.user = user; c->sync.world = world; c->sync.xbuf = exchange; c->sync.xbytes = exchange_bytes;
@@ -1100,6 +1130,7 @@ int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stre
   }
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
   SyncScope sc(c, true);
+  UnscaleScope us(c);
   return backward_block_impl(c, block, dlogits, (hipStream_t)stream, c->side_mode != 2);
 }
 
@@ -1127,6 +1158,7 @@ int fu_backward(fu_ctx* c, const float* dlogits, fu_stream stream) {
   }
   FU_REQUIRE(c->G, "fu_backward: no gradient buffer bound");
   SyncScope sc(c, true);
+  UnscaleScope us(c);
   // whole backward: the side stream (weight gradients) is joined once, after the last block
   const int nblk = num_backward_blocks(c);
   for (int b = 0; b < nblk; ++b) FU_TRY(backward_block_impl(c, b, dlogits, (hipStream_t)stream, b == nblk - 1));
@@ -1221,8 +1253,8 @@ int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* tota
   if (total_flops) *total_flops = fl;
   if (kernel_name)
     *kernel_name = kernel_class == FU_K_CONV3X3
-                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : "k_conv3x3_bf16_fast")
-                       : (c->prec == PREC_F32 ? "k_wgrad_f32" : "k_wgrad_bf16");
+                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : (c->prec == PREC_BF16 ? "k_conv3x3_bf16_fast" : "k_conv3x3_f16_fast"))
+                       : (c->prec == PREC_F32 ? "k_wgrad_f32" : (c->prec == PREC_BF16 ? "k_wgrad_bf16" : "k_wgrad_f16"));
   return FU_OK;
 }
 
@@ -1258,11 +1290,11 @@ int fu_augment(const float* image, const int64_t* target, float* image_out, int6
 }
 
 // ---- single operators --------------------------------------------------------------------------------
-int fu_elem_size(int precision) { return precision == FU_F32 ? 4 : 2; }
+int fu_elem_size(int precision) { return precision == FU_F32 ? 4 : 2; }   /* FU_BF16 and FU_F16: 2 */
 
 static int prec_of(int precision, Prec* p) {
-  FU_REQUIRE(precision == FU_F32 || precision == FU_BF16, "unknown precision %d", precision);
-  *p = precision == FU_F32 ? PREC_F32 : PREC_BF16;
+  FU_REQUIRE(precision == FU_F32 || precision == FU_BF16 || precision == FU_F16, "unknown precision %d", precision);
+  *p = precision == FU_F32 ? PREC_F32 : (precision == FU_BF16 ? PREC_BF16 : PREC_F16);
   return 0;
 }
 

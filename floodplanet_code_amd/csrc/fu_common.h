@@ -8,8 +8,11 @@
 namespace fu {
 
 typedef unsigned short bf16_t;  // raw bf16 storage
+struct f16_t { unsigned short v; };   // raw IEEE fp16 storage (a distinct type, so that the kernels can be instantiated on it)
 
-enum Prec { PREC_F32 = 0, PREC_BF16 = 1 };
+// PREC_F16: fp16 activations / weights / gradient maps on the matrix cores (v_mfma_f32_32x32x16_f16, the bf16 rate), fp32
+// accumulation, statistics, loss and master weights; the gradient maps carry a power-of-two loss scale (see LossScale).
+enum Prec { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
 
 // ---- error plumbing (thread-local message, never exceptions across the ABI) ----------------
 void set_error(const char* fmt, ...);
@@ -51,6 +54,19 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }   // v_cvt_f32_f16
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }  // RNE
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {     // two floats -> packed fp16 pair (RNE)
+  const float2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+}
+__device__ __forceinline__ void unpack_h2(unsigned u, float& a, float& b) {
+  const float2_t v = __builtin_convertvector(__builtin_bit_cast(half2_t, u), float2_t);
+  a = v.x; b = v.y;
+}
+
 template <typename T> struct ElemIO;
 template <> struct ElemIO<float> {
   static constexpr int VEC = 4;  // elements per 16-byte access
@@ -79,6 +95,21 @@ template <> struct ElemIO<bf16_t> {
   }
   __device__ static __forceinline__ float load1(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void store1(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+template <> struct ElemIO<f16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    unpack_h2(t.x, v[0], v[1]); unpack_h2(t.y, v[2], v[3]);
+  }
+  __device__ static __forceinline__ void store4(f16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = pack_h2(v[0], v[1]); t.y = pack_h2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = t;
+  }
+  __device__ static __forceinline__ float load1(const f16_t* p) { return h2f(p->v); }
+  __device__ static __forceinline__ void store1(f16_t* p, float v) { p->v = f2h(v); }
 };
 
 // The activation every consumer re-derives from a stored pre-BN value y: relu(a*y + b), with a = gamma*invstd and
@@ -118,6 +149,19 @@ template <> struct VecIO<bf16_t> {
     t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
     t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
     t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = t;
+  }
+};
+
+template <> struct VecIO<f16_t> {
+  static constexpr int V = 8;
+  __device__ static __forceinline__ void load(const f16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    unpack_h2(t.x, v[0], v[1]); unpack_h2(t.y, v[2], v[3]); unpack_h2(t.z, v[4], v[5]); unpack_h2(t.w, v[6], v[7]);
+  }
+  __device__ static __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack_h2(v[0], v[1]); t.y = pack_h2(v[2], v[3]); t.z = pack_h2(v[4], v[5]); t.w = pack_h2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = t;
   }
 };
@@ -163,6 +207,14 @@ extern thread_local const SyncDesc* g_sync;
 // payload (device, n elements of float or double) -> xbuf, hook, back; no-op without an active descriptor
 int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s);
 static inline int sync_world() { return (g_sync && g_sync->hook) ? g_sync->world : 1; }
+
+// fp16 mode: the gradient maps (fp16) carry a power-of-two loss scale S chosen on the device from max|dL/dlogits| at the
+// start of every backward (launch_loss_scale).  scale[0] = S, scale[1] = 1/S.  The three places that write PARAMETER
+// gradients (weight-gradient transpose + bias tail, BN backward finalize, head backward finalize) multiply by 1/S, so the
+// flat gradient buffer always holds true gradients.  The API layer points g_grad_unscale at scale + 1 for the duration of
+// a backward call in fp16 mode; nullptr (fp32 / bf16) means 1.
+extern thread_local const float* g_grad_unscale;
+int launch_loss_scale(float* dlogits, int64_t n, float* partials /* >= 256 floats */, float* scale /* [2] */, hipStream_t s);
 
 // ---- kernel launchers (implemented in the .hip files) ----------------------------------------
 // All pointers are device pointers; T-typed buffers are `void*` + Prec.
@@ -213,6 +265,16 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
                               hipStream_t s);
 int launch_pack_conv3x3_bf16(const float* w_oihw, int Cout, int cin_real, int cin_pad, bf16_t* wfwd, bf16_t* wdgrad,
                              hipStream_t s);
+// the same sources compiled for IEEE fp16 (fu_conv_bf16.h, -DFU_HALF=1); buffers are raw 16-bit storage
+int conv3x3_num_stat_tiles_f16(int B, int H, int W);
+int64_t conv3x3_wgrad_slab_elems_f16(int Cin, int Cout, int B, int H, int W);
+int launch_conv3x3_f16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
+                       int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s);
+int launch_conv3x3_wgrad_f16(const ConvIn& in, const bf16_t* dy, int Cout, float* slab, float* dw_oihw, int cin_real,
+                             const float* db_partials, int n_db_partials, float* db, int B, int H, int W,
+                             hipStream_t s);
+int launch_pack_conv3x3_f16(const float* w_oihw, int Cout, int cin_real, int cin_pad, bf16_t* wfwd, bf16_t* wdgrad,
+                            hipStream_t s);
 extern int g_bf16_force_cfg;
 
 int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s,

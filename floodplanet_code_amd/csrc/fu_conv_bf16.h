@@ -1,14 +1,51 @@
-// Private declarations shared by the bf16 convolution translation units (fu_conv_bf16.hip, fu_conv_bf16_fast.hip).
+// Private declarations shared by the 16-bit convolution translation units (fu_conv_bf16.hip, fu_conv_bf16_fast.hip).
+//
+// ONE source, TWO element types.  The Makefile compiles both files twice: as they stand (bf16: v_mfma_f32_32x32x16_bf16) and
+// with -DFU_HALF=1 (IEEE fp16: v_mfma_f32_32x32x16_f16, the same MFMA rate).  Tiles, LDS images, schedules, address math
+// and the transposing reads are identical -- a 16-bit element is a 16-bit element -- so the only things that change are
+// the four conversions (f2e / e2f_lo / e2f_hi / pack_e2), the fragment vector type and the MFMA / ds_read_tr builtins,
+// all defined below.  Device buffers stay raw 16-bit storage (`bf16_t` = unsigned short in both builds); the fp16 build's
+// entry points and kernels carry `f16` in their names (the #defines at the end of the FU_HALF block), the testing hooks
+// and their globals live in the bf16 objects only.
 #pragma once
 #include "fu_common.h"
+
+#ifndef FU_HALF
+#define FU_HALF 0
+#endif
+#if FU_HALF
+// names of the fp16 build (the bf16 build keeps the names as written in the sources)
+#define launch_pack_conv3x3_bf16 launch_pack_conv3x3_f16
+#define launch_conv3x3_bf16 launch_conv3x3_f16
+#define launch_conv3x3_wgrad_bf16 launch_conv3x3_wgrad_f16
+#define launch_conv3x3_bf16_fast launch_conv3x3_f16_fast
+#define conv3x3_bf16_fast_eligible conv3x3_f16_fast_eligible
+#define conv3x3_num_stat_tiles_bf16 conv3x3_num_stat_tiles_f16
+#define conv3x3_wgrad_slab_elems_bf16 conv3x3_wgrad_slab_elems_f16
+#define k_pack_bf16 k_pack_f16
+#define k_conv3x3_bf16 k_conv3x3_f16
+#define k_conv3x3_bf16_fast k_conv3x3_f16_fast
+#define k_wgrad_bf16 k_wgrad_f16
+#define k_wgrad_bf16_pp k_wgrad_f16_pp
+#endif
 
 #include <type_traits>
 
 namespace fu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+#if FU_HALF
+typedef _Float16 frag8_t __attribute__((ext_vector_type(8)));     // one MFMA operand fragment: 8 consecutive k per lane
+typedef __fp16 tr4_t __attribute__((ext_vector_type(4)));         // (the element type the ds_read_tr16 builtin is declared with)
+#define FU_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define FU_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4f16(p)
+#else
+typedef __bf16 frag8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 tr4_t __attribute__((ext_vector_type(4)));
+#define FU_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FU_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p)
+#endif
 
 // compile-time loop: every array index below is a constant expression, so the staging registers are never
 // demoted to scratch (runtime-indexed private arrays are -- cdna guide rule 20)
@@ -30,24 +67,42 @@ __device__ __forceinline__ void static_for(F&& f) {
   } while (0)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 #ifdef __HIPCC__
-__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32
+// ---- the element conversions (the only arithmetic that depends on the 16-bit format) ----
+#if FU_HALF
+typedef _Float16 e16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2e(float f) { return f2h(f); }                                   // RNE
+__device__ __forceinline__ float e2f_lo(unsigned v) { return h2f((unsigned short)(v & 0xffffu)); }  // v_cvt_f32_f16
+__device__ __forceinline__ float e2f_hi(unsigned v) { return h2f((unsigned short)(v >> 16)); }      // v_cvt_f32_f16 sdwa WORD_1
+__device__ __forceinline__ f32x2 e2f_pair(unsigned v) {
+  return __builtin_convertvector(__builtin_bit_cast(e16x2, v), f32x2);
 }
-
-// relu(a * x + b) on the two bf16 channels of one dword; one rounding to bf16
-__device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
+#else
+typedef __bf16 e16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2e(float f) { return f2bf(f); }
+__device__ __forceinline__ float e2f_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float e2f_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ f32x2 e2f_pair(unsigned v) {
   f32x2 x;
   x.x = __uint_as_float(v << 16);
   x.y = __uint_as_float(v & 0xffff0000u);
-  x = __builtin_elementwise_fma(a, x, b);                                    // v_pk_fma_f32 (= bn_act_fused per lane)
-  const s16x2 h = __builtin_bit_cast(s16x2, pack_bf16x2(x));
-  const s16x2 z = {0, 0};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: bf16 sign test = relu
+  return x;
 }
+#endif
+__device__ __forceinline__ unsigned pack_e2(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, e16x2));    // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (RNE)
+}
+
+// relu(a * x + b) on the two 16-bit channels of one dword; one rounding to the element type
+__device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
+  f32x2 x = e2f_pair(v);
+  x = __builtin_elementwise_fma(a, x, b);                                    // v_pk_fma_f32 (= bn_act_fused per lane)
+  const s16x2 h = __builtin_bit_cast(s16x2, pack_e2(x));
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(h, z));      // v_pk_max_i16: the sign bit test of bf16 AND of
+}                                                                            // fp16 (sign-magnitude, bit 15) = relu
 
 #endif
 
@@ -68,3 +123,4 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
 
 }  // namespace fu
+

@@ -33,7 +33,7 @@ __global__ void k_pack_bf16(const float* __restrict__ w, int Cout, int cin_real,
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
     const float v = ci < cin_real ? w[((int64_t)co * cin_real + ci) * 9 + tap] : 0.f;
-    const bf16_t h = f2bf(v);
+    const bf16_t h = f2e(v);
     if (wf) wf[idx] = h;                                                    // [tap][co][ci]
     if (wd) wd[((int64_t)(8 - tap) * cin_pad + ci) * Cout + co] = h;        // [8-tap][ci][co]
   }
@@ -68,19 +68,19 @@ struct BCfg {
 __device__ __forceinline__ uint4 bn_relu_pack8(uint4 v, const float4& a0, const float4& a1, const float4& b0,
                                                const float4& b1) {
   float x[8];
-  x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
-  x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
-  x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
-  x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
+  x[0] = e2f_lo(v.x); x[1] = e2f_hi(v.x);
+  x[2] = e2f_lo(v.y); x[3] = e2f_hi(v.y);
+  x[4] = e2f_lo(v.z); x[5] = e2f_hi(v.z);
+  x[6] = e2f_lo(v.w); x[7] = e2f_hi(v.w);
   x[0] = bn_act_fused(a0.x, x[0], b0.x); x[1] = bn_act_fused(a0.y, x[1], b0.y);
   x[2] = bn_act_fused(a0.z, x[2], b0.z); x[3] = bn_act_fused(a0.w, x[3], b0.w);
   x[4] = bn_act_fused(a1.x, x[4], b1.x); x[5] = bn_act_fused(a1.y, x[5], b1.y);
   x[6] = bn_act_fused(a1.z, x[6], b1.z); x[7] = bn_act_fused(a1.w, x[7], b1.w);
   uint4 o;
-  o.x = (unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16);
-  o.y = (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16);
-  o.z = (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16);
-  o.w = (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16);
+  o.x = (unsigned)f2e(x[0]) | ((unsigned)f2e(x[1]) << 16);
+  o.y = (unsigned)f2e(x[2]) | ((unsigned)f2e(x[3]) << 16);
+  o.z = (unsigned)f2e(x[4]) | ((unsigned)f2e(x[5]) << 16);
+  o.w = (unsigned)f2e(x[6]) | ((unsigned)f2e(x[7]) << 16);
   return o;
 }
 
@@ -230,16 +230,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
     // 18 k-steps (9 taps x 2 halves of the 32-channel chunk), software-pipelined by hand: the fragments of step
     // s+1 are requested from LDS before the MFMAs of step s are issued (hipcc otherwise issues each step's
     // ds_reads just in time and exposes one LDS latency per 4 MFMAs).
-    bf16x8 af[2][2], bfr[2][NTW];
+    frag8_t af[2][2], bfr[2][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
       constexpr int tap = st >> 1, ks = st & 1;
       constexpr int toff = ((tap / 3) * HWd + (tap % 3)) * KCP + ks * 16;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
+      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *reinterpret_cast<const frag8_t*>(sA + aoff[mt] + toff);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
-        bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+        bfr[buf][nt] = *reinterpret_cast<const frag8_t*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
     };
     load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     static_for<0, 18>([&](auto S) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = FU_MFMA32(af[buf][mt], bfr[buf][nt], acc[mt][nt]);
     });
   }
 
@@ -294,10 +294,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
         const float s23 = q_even ? v[3] : v[2];
         const float r01 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s01), 0xB1, 0xF, 0xF, true));
         const float r23 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s23), 0xB1, 0xF, 0xF, true));
-        const unsigned A = q_even ? ((unsigned)f2bf(v[0]) | ((unsigned)f2bf(r01) << 16))
-                                  : ((unsigned)f2bf(r01) | ((unsigned)f2bf(v[1]) << 16));
-        const unsigned Bq = q_even ? ((unsigned)f2bf(v[2]) | ((unsigned)f2bf(r23) << 16))
-                                   : ((unsigned)f2bf(r23) | ((unsigned)f2bf(v[3]) << 16));
+        const unsigned A = q_even ? ((unsigned)f2e(v[0]) | ((unsigned)f2e(r01) << 16))
+                                  : ((unsigned)f2e(r01) | ((unsigned)f2e(v[1]) << 16));
+        const unsigned Bq = q_even ? ((unsigned)f2e(v[2]) | ((unsigned)f2e(r23) << 16))
+                                   : ((unsigned)f2e(r23) | ((unsigned)f2e(v[3]) << 16));
         // level 2: pairs of channel pairs
         const unsigned send = q_lo ? Bq : A;
         const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);
@@ -362,10 +362,15 @@ static int launch_cfg(BConvP& P, hipStream_t s) {
   return 0;
 }
 
+#if FU_HALF      // the hooks live in the bf16 objects; the fp16 kernels obey the same switches
+extern int g_bf16_force_general, g_bf16_force_full_taps, g_wgrad_force_lockstep;
+extern unsigned long long* g_conv_dbg;
+#else
 int g_bf16_force_cfg = -1;  // testing hook: 0 = 256x64 tile, 2 = 256x32 tile
 int g_bf16_force_general = 0;   // testing hook (fu_test_force_general_conv): skip the aligned-shape fast kernel
 int g_bf16_force_full_taps = 0; // testing hook (fu_test_force_full_taps): embedded 1x1 convs run all nine taps
 unsigned long long* g_conv_dbg = nullptr;
+#endif
 
 int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, bf16_t* dst0, int D0, bf16_t* dst1,
                         int D1, float* stats, int* n_stat_tiles, int B, int H, int W, hipStream_t s) {
@@ -417,12 +422,11 @@ struct BWgP {
 // Two transposing reads -> one MFMA fragment.  NOTE (hipcc / ROCm 7.2): the v4i16 form of the builtin followed by
 // per-element bit casts to __bf16 is miscompiled (element 0 is replicated); the v4bf16 form + shufflevector is correct
 // (checked on hardware, tools/probes/tr_probe3.hip).
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-  const bf16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
-  return __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7);
+__device__ __forceinline__ frag8_t tr_frag(const bf16_t* p0, const bf16_t* p1) {
+  typedef __attribute__((address_space(3))) tr4_t lds_tr4;
+  const tr4_t v = FU_TR16((lds_tr4*)p0);
+  const tr4_t w = FU_TR16((lds_tr4*)p1);
+  return __builtin_bit_cast(frag8_t, __builtin_shufflevector(v, w, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // WMI waves along c_in (32 each) x 2 waves along c_out (32 each); pixel stage = PTH x 16 pixels with halo.
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
     // Walk the halo rows once: the X fragment of (halo row hr, column shift dx) feeds up to three taps
     // (dy = 0..2 with pixel row r = hr - dy), so every fragment is fetched from LDS once; dy fragments of the last
     // three pixel rows stay in a 4-deep register ring.  Next step's fragment is requested before this step's MFMAs.
-    bf16x8 Af[2], Bf[4];
+    frag8_t Af[2], Bf[4];
     auto loadA = [&](auto Sc) {
       constexpr int st = decltype(Sc)::value, hr = st / 3, dx = st % 3;
       const bf16_t* ad = sX + (hr * HWd + tr_px + dx) * RSX + mi * 32 + tr_ch;
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
         static_for<0, 3>([&](auto DY) {
           constexpr int dy = decltype(DY)::value, r = hr - dy;
           if constexpr (r >= 0 && r < PTH)
-            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+            acc[dy * 3 + dx] = FU_MFMA32(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx]);
         });
       });
     } else {
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
           loadB(std::integral_constant<int, r + 1>{});
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[(3 * (r + 1) + 1) & 1], Bf[r & 3], acc[0], 0, 0, 0);
+        acc[0] = FU_MFMA32(Af[(3 * (r + 1) + 1) & 1], Bf[r & 3], acc[0]);
       });
     }
 #ifdef FU_CONV_STAMPS
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   };
   auto mfma_stage = [&](const bf16_t* sX) {
     const bf16_t* sD = sX + NHP * RSX;
-    bf16x8 Af[2], Bf[4];
+    frag8_t Af[2], Bf[4];
     auto loadA = [&](auto Sc) {
       constexpr int st = decltype(Sc)::value, hr = st / 3, dx = st % 3, c = hr * HWd + dx;
       const bf16_t* ad = sX + c * RSX + aoff[c & 3];
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
       static_for<0, 3>([&](auto DY) {
         constexpr int dy = decltype(DY)::value, r = hr - dy;
         if constexpr (r >= 0 && r < PTH)
-          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx], 0, 0, 0);
+          acc[dy * 3 + dx] = FU_MFMA32(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx]);
       });
     });
   };
@@ -947,7 +951,9 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
 #ifndef FU_WGRAD_LOCKSTEP_DEFAULT
 #define FU_WGRAD_LOCKSTEP_DEFAULT 0   // A/B builds: -DFU_WGRAD_LOCKSTEP_DEFAULT=1
 #endif
+#if !FU_HALF
 int g_wgrad_force_lockstep = FU_WGRAD_LOCKSTEP_DEFAULT;   // testing hook (fu_test_force_lockstep_wgrad): k_wgrad_bf16<4,8> instead of the ping-pong kernel
+#endif
 
 static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
   using Cfg = WPCfg;
@@ -1010,7 +1016,9 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
 
 }  // namespace fu
 
+#if !FU_HALF
 extern "C" void fu_test_force_general_conv(int on) { fu::g_bf16_force_general = on; }
 extern "C" void fu_test_force_lockstep_wgrad(int on) { fu::g_wgrad_force_lockstep = on; }
 extern "C" void fu_test_force_full_taps(int on) { fu::g_bf16_force_full_taps = on; }
 extern "C" void fu_debug_set_conv_stamps(void* p) { fu::g_conv_dbg = (unsigned long long*)p; }
+#endif

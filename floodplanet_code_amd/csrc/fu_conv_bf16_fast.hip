@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
     // (tall tile: 128 accumulator registers; a second fragment buffer would not fit in 256 registers -- its 8 MFMAs per
     //  k-step and the co-resident wave cover the LDS latency instead of a one-step prefetch)
     constexpr int FD = MT == 4 ? 0 : FU_FAST_FRAG_DIST, NB = FD + 1;
-    bf16x8 af[NB][MT], bfr[NB][NTW];
+    frag8_t af[NB][MT], bfr[NB][NTW];
     auto load_frags = [&](auto Sc, auto Bc) {
       constexpr int st = decltype(Sc)::value, buf = decltype(Bc)::value;
       constexpr int tap = st / Cfg::KSTEPS, ks = st % Cfg::KSTEPS;    // tap = index inside sW
@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
       if constexpr (MT == 4) {   // no prefetch buffer: the weight fragments first, so that the first MFMAs of the step
 #pragma unroll                   // wait for 3 of the 6 reads only (FU_TALL_B_FIRST)
         for (int nt = 0; nt < NTW; ++nt)
-          bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+          bfr[buf][nt] = *reinterpret_cast<const frag8_t*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
       }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + toff);
+      for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *reinterpret_cast<const frag8_t*>(sA + aoff[mt] + toff);
       if constexpr (MT != 4) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
+          bfr[buf][nt] = *reinterpret_cast<const frag8_t*>(sW + tap * BN * KCP + boff[nt] + ks * 16);
       }
     };
     static_for<0, FD>([&](auto Sc) { load_frags(Sc, std::integral_constant<int, decltype(Sc)::value % NB>{}); });
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][mt], bfr[buf][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = FU_MFMA32(af[buf][mt], bfr[buf][nt], acc[mt][nt]);
       if constexpr (LOADS > 0)
         static_for<0, LOADS>([&](auto J) {
           constexpr int sl = st * LOADS + decltype(J)::value;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
             }
           }
           if constexpr (BIAS) { a01 += bias2; a23 += bias2; }
-          const unsigned p01 = pack_bf16x2(a01), p23 = pack_bf16x2(a23);
+          const unsigned p01 = pack_e2(a01), p23 = pack_e2(a23);
           const unsigned r01 = (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xF, 0xF, true);   // quad xor 1
           const unsigned r23 = (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xF, 0xF, true);
           const unsigned A = __builtin_amdgcn_perm(r01, p01, sel1);     // pixel (qj & 1),     channel pair
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
             s2 += a;
             q2 = a * a + q2;
             if constexpr (BIAS) a += bias2;
-            const unsigned pk = pack_bf16x2(a);
+            const unsigned pk = pack_e2(a);
             const unsigned rv = (unsigned)__builtin_amdgcn_mov_dpp((int)pk, 0xB1, 0xF, 0xF, true);   // quad xor 1
             E[t] = __builtin_amdgcn_perm(rv, pk, sel1);      // even lane: pixel 2t, odd lane: pixel 2t + 1 (channel pair)
           }
@@ -522,7 +522,11 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void k_conv3x3_bf16_fast(BCon
 #ifndef FU_TILE_MODE_DEFAULT
 #define FU_TILE_MODE_DEFAULT 0
 #endif
+#if FU_HALF
+extern int g_bf16_tile_mode;
+#else
 int g_bf16_tile_mode = FU_TILE_MODE_DEFAULT;   // 0 = heuristic, 1 = never the tall tile, 2 = tall wherever 64-channel tiles run
+#endif
 
 bool conv3x3_bf16_fast_eligible(const BConvP& P) {
   const int64_t px = (int64_t)P.B * P.H * P.W;
@@ -577,4 +581,6 @@ int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
 
 }  // namespace fu
 
+#if !FU_HALF
 extern "C" void fu_test_conv_tile_mode(int mode) { fu::g_bf16_tile_mode = mode; }
+#endif

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void k_wgrad_f32(WgP P) {
 template <int SL>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cin, int Cout,
                                                       int cin_real, float* __restrict__ dw,
-                                                      const float* __restrict__ dbp, int ndb, float* __restrict__ db) {
+                                                      const float* __restrict__ dbp, int ndb, float* __restrict__ db,
+                                                      const float* __restrict__ unscale) {
   constexpr int COLS = 256 / SL, ELEMS = 4 * COLS;
   __shared__ float sm[SL][ELEMS];
   const int64_t nSlab = (int64_t)9 * Cin * Cout;          // elements of one slab ([tap][ci][co], Cout % 4 == 0)
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += smd[k][c16];
+      if (unscale) t *= (double)*unscale;       // fp16 mode: dy carried the loss scale
       db[co] = (float)t;
     }
   }
@@ -483,8 +485,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // packed [tap][Cin][Cout] (slab 0 after the reduce) -> dw OIHW [Cout][cin_real][9].
 // block tile: 32 co x 8 ci x 9 taps through LDS: 128-byte reads along co, 288-byte writes along (ci, tap).
 __global__ __launch_bounds__(256) void k_wgrad_transpose(const float* __restrict__ packed, int Cin, int Cout,
-                                                         int cin_real, float* __restrict__ dw) {
+                                                         int cin_real, float* __restrict__ dw,
+                                                         const float* __restrict__ unscale) {
   __shared__ float t[72][33];
+  const float us = unscale ? *unscale : 1.f;      // fp16 mode: 1 / loss scale (a power of two: exact)
   const int nCo = (Cout + 31) / 32;
   const int co0 = (blockIdx.x % nCo) * 32, ci0 = (blockIdx.x / nCo) * 8;
   for (int i = threadIdx.x; i < 72 * 32; i += 256) {
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void k_wgrad_transpose(const float* __restrict
     const int c = i / 72, j = i - c * 72;        // j = ci_local*9 + tap  (OIHW order inside the tile)
     const int cil = j / 9, tap = j - cil * 9;
     const int ci = ci0 + cil, co = co0 + c;
-    if (ci < cin_real && co < Cout) dw[((int64_t)co * cin_real + ci) * 9 + tap] = t[tap * 8 + cil][c];
+    if (ci < cin_real && co < Cout) dw[((int64_t)co * cin_real + ci) * 9 + tap] = t[tap * 8 + cil][c] * us;
   }
 }
 
@@ -508,7 +512,7 @@ static int launch_wgrad_reduce_sl(const float* slab, int S, int Cin, int Cout, i
   const int64_t nSlab = (int64_t)9 * Cin * Cout;
   const int64_t blocks = (nSlab + ELEMS - 1) / ELEMS + (db ? (Cout + 15) / 16 : 0);
   hipLaunchKernelGGL(k_wgrad_reduce<SL>, dim3((unsigned)blocks), dim3(256), 0, s, slab, S, Cin, Cout, cin_real, dw,
-                     dbp, ndb, db);
+                     dbp, ndb, db, g_grad_unscale);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -521,7 +525,7 @@ int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_rea
   else st = launch_wgrad_reduce_sl<1>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
   if (st) return st;
   const int blocks = ceil_div(Cout, 32) * ceil_div(Cin, 8);
-  hipLaunchKernelGGL(k_wgrad_transpose, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw);
+  hipLaunchKernelGGL(k_wgrad_transpose, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw, g_grad_unscale);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -9,6 +9,7 @@
 namespace fu {
 
 thread_local const SyncDesc* g_sync = nullptr;
+thread_local const float* g_grad_unscale = nullptr;
 
 int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s) {
   const SyncDesc* d = g_sync;
@@ -93,8 +94,11 @@ int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H
   src += (int64_t)src_channel_offset * H * W;
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, C, H * W, c_pad, total, srcC);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_nchw_to_nhwc<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, C, H * W, c_pad, total,
+                       srcC);
+  else
+    hipLaunchKernelGGL(k_nchw_to_nhwc<f16_t>, dim3(g), dim3(256), 0, s, src, (f16_t*)dst, C, H * W, c_pad, total,
                        srcC);
   FU_LAUNCH_CHECK();
   return 0;
@@ -105,8 +109,11 @@ int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H
   const int g = grid_for(total, 256);
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_nhwc_to_nchw<float>, dim3(g), dim3(256), 0, s, (const float*)src, dst, C, H * W, c_pad, total);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_nhwc_to_nchw<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, dst, C, H * W, c_pad,
+                       total);
+  else
+    hipLaunchKernelGGL(k_nhwc_to_nchw<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)src, dst, C, H * W, c_pad,
                        total);
   FU_LAUNCH_CHECK();
   return 0;
@@ -300,6 +307,7 @@ __global__ void k_bn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ y
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ dpart, int G, int C,
                                                          double count, double grad_share,
+                                                         const float* __restrict__ unscale,
                                                          float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
   const int g = threadIdx.x & 31;
@@ -312,8 +320,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restric
   if (c >= C || g != 0) return;
   // (exact DP: S1, S2 are sums over all ranks; the parameter gradients are summed over the ranks afterwards, so each
   //  rank contributes 1/world of them)
-  if (dbeta) dbeta[c] = (float)(S1 * grad_share);
-  if (dgamma) dgamma[c] = (float)(S2 * grad_share);
+  const double us = unscale ? (double)*unscale : 1.0;      // fp16 mode: g carries the loss scale, the parameters' gradients do not
+  if (dbeta) dbeta[c] = (float)(S1 * grad_share * us);
+  if (dgamma) dgamma[c] = (float)(S2 * grad_share * us);
   coef[c * 2 + 0] = (float)(S1 / count);
   coef[c * 2 + 1] = (float)(S2 / count);
 }
@@ -386,22 +395,28 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const float*)g, (const float*)y,
                        C, npix, a, b, mean, invstd, partials);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const bf16_t*)g,
                        (const bf16_t*)y, C, npix, a, b, mean, invstd, partials);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_reduce<f16_t>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const f16_t*)g,
+                       (const f16_t*)y, C, npix, a, b, mean, invstd, partials);
   FU_LAUNCH_CHECK();
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
   FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global sums of g and g*xhat
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
-                     (double)npix * sync_world(), 1.0 / sync_world(), dgamma, dbeta, coef);
+                     (double)npix * sync_world(), 1.0 / sync_world(), g_grad_unscale, dgamma, dbeta, coef);
   FU_LAUNCH_CHECK();
   const size_t sh2 = (size_t)rows * C * sizeof(float);
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(nb), dim3(BNB_THREADS), sh2, s, (float*)g, (const float*)y, C, npix,
                        a, b, mean, invstd, coef, db_partials);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(nb), dim3(BNB_THREADS), sh2, s, (bf16_t*)g, (const bf16_t*)y, C,
+                       npix, a, b, mean, invstd, coef, db_partials);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<f16_t>, dim3(nb), dim3(BNB_THREADS), sh2, s, (f16_t*)g, (const f16_t*)y, C,
                        npix, a, b, mean, invstd, coef, db_partials);
   FU_LAUNCH_CHECK();
   *n_db_partials = nb;
@@ -525,9 +540,13 @@ int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, voi
     FU_REQUIRE(row_grid<float>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_maxpool2<float>, g, dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, Ho, Wo, CV,
                        rcp);
-  } else {
+  } else if (p == PREC_BF16) {
     FU_REQUIRE(row_grid<bf16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_maxpool2<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C, Ho, Wo,
+                       CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<f16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2<f16_t>, g, dim3(256), 0, s, (const f16_t*)src, a, b, (f16_t*)dst, H, W, C, Ho, Wo,
                        CV, rcp);
   }
   FU_LAUNCH_CHECK();
@@ -542,10 +561,14 @@ int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const floa
     FU_REQUIRE(row_grid<float>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_maxpool2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (const float*)y_src, a, b,
                        (float*)g_src, H, W, C, Ho, Wo, CV, rcp);
-  } else {
+  } else if (p == PREC_BF16) {
     FU_REQUIRE(row_grid<bf16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_maxpool2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (const bf16_t*)y_src, a, b,
                        (bf16_t*)g_src, H, W, C, Ho, Wo, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<f16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_maxpool2_bwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)g_dst, (const f16_t*)y_src, a, b,
+                       (f16_t*)g_src, H, W, C, Ho, Wo, CV, rcp);
   }
   FU_LAUNCH_CHECK();
   return 0;
@@ -632,9 +655,13 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
     FU_REQUIRE(row_grid<float>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
     hipLaunchKernelGGL(k_upsample2<float>, g, dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, outH, outW,
                        py0, px0, t, CV, rcp);
-  } else {
+  } else if (p == PREC_BF16) {
     FU_REQUIRE(row_grid<bf16_t>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
     hipLaunchKernelGGL(k_upsample2<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<f16_t>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
+    hipLaunchKernelGGL(k_upsample2<f16_t>, g, dim3(256), 0, s, (const f16_t*)src, a, b, (f16_t*)dst, H, W, C, outH,
                        outW, py0, px0, t, CV, rcp);
   }
   FU_LAUNCH_CHECK();
@@ -649,9 +676,13 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
     FU_REQUIRE(row_grid<float>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_upsample2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C, outH,
                        outW, py0, px0, t, CV, rcp);
-  } else {
+  } else if (p == PREC_BF16) {
     FU_REQUIRE(row_grid<bf16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
     hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<f16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)g_dst, (f16_t*)g_src, H, W, C, outH,
                        outW, py0, px0, t, CV, rcp);
   }
   FU_LAUNCH_CHECK();
@@ -780,8 +811,11 @@ int launch_zero_stuff(Prec p, const void* src, const float* a, const float* b, v
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_zero_stuff<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C,
                        outH, outW, py0, px0, total);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_zero_stuff<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
+                       outH, outW, py0, px0, total);
+  else
+    hipLaunchKernelGGL(k_zero_stuff<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)src, a, b, (f16_t*)dst, H, W, C,
                        outH, outW, py0, px0, total);
   FU_LAUNCH_CHECK();
   return 0;
@@ -794,8 +828,11 @@ int launch_gather_even(Prec p, const void* gu, void* gsrc, int B, int H, int W, 
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_gather_even<float>, dim3(g), dim3(256), 0, s, (const float*)gu, (float*)gsrc, H, W, C, outH,
                        outW, py0, px0, total);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_gather_even<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)gsrc, H, W, C, outH,
+                       outW, py0, px0, total);
+  else
+    hipLaunchKernelGGL(k_gather_even<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)gu, (f16_t*)gsrc, H, W, C, outH,
                        outW, py0, px0, total);
   FU_LAUNCH_CHECK();
   return 0;
@@ -808,8 +845,11 @@ int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, in
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_zero_border<float>, dim3(g), dim3(256), 0, s, (float*)t, 2 * H, 2 * W, C, outH, outW, py0, px0,
                        total);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_zero_border<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)t, 2 * H, 2 * W, C, outH, outW, py0,
+                       px0, total);
+  else
+    hipLaunchKernelGGL(k_zero_border<f16_t>, dim3(g), dim3(256), 0, s, (f16_t*)t, 2 * H, 2 * W, C, outH, outW, py0,
                        px0, total);
   FU_LAUNCH_CHECK();
   return 0;
@@ -825,8 +865,11 @@ int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, floa
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_channel_partial_sums<float>, dim3((unsigned)nb), dim3(BNB_THREADS), sh, s, (const float*)g, C,
                        npix, partials);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL(k_channel_partial_sums<bf16_t>, dim3((unsigned)nb), dim3(BNB_THREADS), sh, s, (const bf16_t*)g,
+                       C, npix, partials);
+  else
+    hipLaunchKernelGGL(k_channel_partial_sums<f16_t>, dim3((unsigned)nb), dim3(BNB_THREADS), sh, s, (const f16_t*)g,
                        C, npix, partials);
   FU_LAUNCH_CHECK();
   *n_partials = (int)nb;
@@ -878,9 +921,12 @@ int launch_copy_channels(Prec p, const void* src, int srcC, int src_off, const f
   if (p == PREC_F32)
     hipLaunchKernelGGL((k_copy_channels<float, 4>), dim3(g), dim3(256), 0, s, (const float*)src, srcC, src_off, a, b,
                        (float*)dst, dstC, dst_off, C, npix);
-  else
+  else if (p == PREC_BF16)
     hipLaunchKernelGGL((k_copy_channels<bf16_t, 8>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, srcC, src_off, a, b,
                        (bf16_t*)dst, dstC, dst_off, C, npix);
+  else
+    hipLaunchKernelGGL((k_copy_channels<f16_t, 8>), dim3(g), dim3(256), 0, s, (const f16_t*)src, srcC, src_off, a, b,
+                       (f16_t*)dst, dstC, dst_off, C, npix);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -1027,9 +1073,12 @@ int launch_head_fwd(Prec p, const void* y, const float* a, const float* b, const
   if (p == PREC_F32) {
     FU_REQUIRE(head_geometry<float>(C, &LPP), "head: base channels must be 4, 8, 16, 32 or 64 in fp32 (got %d)", C);
     launch_head_fwd_t<float>((const float*)y, a, b, w, bias, C, ncls, B, HW, LPP, logits_nhwc, logits_nchw, s);
-  } else {
+  } else if (p == PREC_BF16) {
     FU_REQUIRE(head_geometry<bf16_t>(C, &LPP), "head: base channels must be 8, 16, 32, 64 or 128 in bf16 (got %d)", C);
     launch_head_fwd_t<bf16_t>((const bf16_t*)y, a, b, w, bias, C, ncls, B, HW, LPP, logits_nhwc, logits_nchw, s);
+  } else {
+    FU_REQUIRE(head_geometry<f16_t>(C, &LPP), "head: base channels must be 8, 16, 32, 64 or 128 in fp16 (got %d)", C);
+    launch_head_fwd_t<f16_t>((const f16_t*)y, a, b, w, bias, C, ncls, B, HW, LPP, logits_nhwc, logits_nchw, s);
   }
   FU_LAUNCH_CHECK();
   return 0;
@@ -1395,7 +1444,8 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, 
 }
 
 __global__ __launch_bounds__(256) void k_head_bwd_finalize(const float* __restrict__ partials, int nblk, int C,
-                                                           int ncls, float* __restrict__ dw, float* __restrict__ db) {
+                                                           int ncls, const float* __restrict__ unscale,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
   // 8 elements per block, 32 lanes per element; each lane sums every 32nd block partial, fixed xor tree at the end
   const int stride = ncls * C + ncls;
   const int g = threadIdx.x & 31;
@@ -1407,6 +1457,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_finalize(const float* __restri
   }
   s = half_wave_sum(s);
   if (e >= stride || g != 0) return;
+  if (unscale) s *= (double)*unscale;       // fp16 mode: dlogits carried the loss scale
   if (e < ncls * C) dw[e] = (float)s;
   else db[e - ncls * C] = (float)s;
 }
@@ -1418,7 +1469,8 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
   FU_REQUIRE(npix < ((int64_t)1 << 31), "head_bwd: too many pixels");
   int LPP;
   if (p == PREC_F32) FU_REQUIRE(head_geometry<float>(C, &LPP), "head_bwd: unsupported channel count %d", C);
-  else FU_REQUIRE(head_geometry<bf16_t>(C, &LPP), "head_bwd: unsupported channel count %d", C);
+  else if (p == PREC_BF16) FU_REQUIRE(head_geometry<bf16_t>(C, &LPP), "head_bwd: unsupported channel count %d", C);
+  else FU_REQUIRE(head_geometry<f16_t>(C, &LPP), "head_bwd: unsupported channel count %d", C);
   constexpr int U = 4;
   const int ppb = 256 / LPP;
   int nblk = (int)ceil_div64(npix, (int64_t)ppb * U);
@@ -1437,7 +1489,7 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
       case 4: FU_HEAD_BWD(float, 4); break;
       default: FU_HEAD_BWD(float, 0); break;
     }
-  } else {
+  } else if (p == PREC_BF16) {
     switch (ncls) {
       case 1: FU_HEAD_BWD(bf16_t, 1); break;
       case 2: FU_HEAD_BWD(bf16_t, 2); break;
@@ -1445,10 +1497,19 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
       case 4: FU_HEAD_BWD(bf16_t, 4); break;
       default: FU_HEAD_BWD(bf16_t, 0); break;
     }
+  } else {
+    switch (ncls) {
+      case 1: FU_HEAD_BWD(f16_t, 1); break;
+      case 2: FU_HEAD_BWD(f16_t, 2); break;
+      case 3: FU_HEAD_BWD(f16_t, 3); break;
+      case 4: FU_HEAD_BWD(f16_t, 4); break;
+      default: FU_HEAD_BWD(f16_t, 0); break;
+    }
   }
 #undef FU_HEAD_BWD
   FU_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 8)), dim3(256), 0, s, partials, nblk, C, ncls, dw, db);
+  hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 8)), dim3(256), 0, s, partials, nblk, C, ncls,
+                     g_grad_unscale, dw, db);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -1599,6 +1660,49 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double 
   hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1),
                      (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size),
                      (float)grad_scale);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 loss scale (fu_common.h, g_grad_unscale): S = 2^k with max|dl| * S in [2^5, 2^6) -- three decades of headroom to
+// fp16's 65504 for what the backward chain multiplies on top, while the bulk of the gradient maps stays in fp16's normal
+// range.  Chosen from the data on the device (no host read, any loss, any upstream scale), applied in place.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_absmax_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = fabsf(x[i]);
+    m = (v <= 3.0e38f && v > m) ? v : m;        // (non-finite entries do not define the scale)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void k_loss_scale_apply(float* __restrict__ x, int64_t n, const float* __restrict__ partials,
+                                                          int nPart, float* __restrict__ scale) {
+  __shared__ float sm[4];
+  float m = threadIdx.x < nPart ? partials[threadIdx.x] : 0.f;      // nPart <= 256
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  int e = 0;
+  if (m > 0.f) { (void)frexpf(m, &e); e = 6 - e; }                  // m = f * 2^e', f in [0.5, 1)  ->  m * 2^(6 - e') in [32, 64)
+  e = min(max(e, -60), 60);
+  const float S = ldexpf(1.f, e);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = ldexpf(1.f, -e); }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= S;
+}
+int launch_loss_scale(float* dlogits, int64_t n, float* partials, float* scale, hipStream_t s) {
+  const int g = grid_for(n, 256 * 16, 256);
+  hipLaunchKernelGGL(k_absmax_partial, dim3(g), dim3(256), 0, s, dlogits, n, partials);
+  FU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_loss_scale_apply, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, s, dlogits, n, partials, g, scale);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -59,7 +59,13 @@ enum fu_status {
 
 enum fu_precision {
   FU_F32 = 0, /* fp32 storage, fp32 MFMA (exact fmaf chains): the 1e-4 parity mode */
-  FU_BF16 = 1 /* bf16 activations/weights, fp32 accumulate, fp32 master weights / BN / loss */
+  FU_BF16 = 1, /* bf16 activations/weights, fp32 accumulate, fp32 master weights / BN / loss */
+  FU_F16 = 2   /* IEEE fp16 activations / weights / gradient maps on the matrix cores (v_mfma_f32_32x32x16_f16, the bf16
+                * rate), fp32 accumulation, fp32 master weights, BN statistics, loss and Dice reductions (BASELINE configs[3]:
+                * "mixed fp16 with fp32 Dice reduction").  The gradient maps carry a power-of-two loss scale chosen on the
+                * device from max|dL/dlogits| at the start of every backward and removed where parameter gradients are
+                * written: the flat gradient buffer holds true gradients, no caller-side GradScaler is needed.  Inputs are
+                * expected in fp16's range (the reference scales every sensor to [0, 1], datasets/floodplanet.py:347-525). */
 };
 
 enum fu_loss_kind {

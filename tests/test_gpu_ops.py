@@ -179,12 +179,26 @@ BF_SHAPES = [
 ]
 
 
+# the 16-bit kernels exist for two element types (same sources, fu_conv_bf16.h): every test below runs on both.
+# eps = the element type's rounding unit (bf16: 8 significant bits, fp16: 11)
+LOWP = {"bf16": dict(code=_lib.FU_BF16, dt=torch.bfloat16, eps=2.0 ** -8),
+        "fp16": dict(code=_lib.FU_F16, dt=torch.float16, eps=2.0 ** -11)}
+_cur = dict(LOWP["bf16"])
+
+
+@pytest.fixture(params=["bf16", "fp16"])
+def lowp(request):
+    _cur.update(LOWP[request.param])
+    yield request.param
+    _cur.update(LOWP["bf16"])
+
+
 def bf(x):
-    return x.to(torch.bfloat16).float()
+    return x.to(_cur["dt"]).float()
 
 
 def nhwc_bf(x):
-    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    return x.permute(0, 2, 3, 1).contiguous().to(_cur["dt"]).to(DEV)
 
 
 def nchw_bf(x):
@@ -204,7 +218,7 @@ def conv_path(request):
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_forward_and_stats(shape, conv_path):
+def test_conv3x3_bf16_forward_and_stats(shape, conv_path, lowp):
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape)
@@ -216,35 +230,35 @@ def test_conv3x3_bf16_forward_and_stats(shape, conv_path):
     d0, d1 = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None)
     da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
     dw_, dbias = w.to(DEV), bias.to(DEV)
-    y = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty(B, H, W, Cout, device=DEV, dtype=_cur["dt"])
     ssum = torch.empty(Cout, device=DEV)
     ssq = torch.empty(Cout, device=DEV)
-    check(lib.fu_op_conv3x3_fwd(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(dw_), ptr(dbias), ptr(y), Cout,
+    check(lib.fu_op_conv3x3_fwd(_cur["code"], ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(dw_), ptr(dbias), ptr(y), Cout,
                                 B, H, W, ptr(ssum), ptr(ssq), stream()))
     torch.cuda.synchronize()
     out = nchw_bf(y)
     full = ref + bias.view(1, -1, 1, 1)
-    assert (out - full).abs().max().item() <= 2.0 ** -7 * max(1.0, full.abs().max().item())
-    assert rel_err(out, full) < 4e-3
+    assert (out - full).abs().max().item() <= 2 * _cur["eps"] * max(1.0, full.abs().max().item())
+    assert rel_err(out, full) < _cur["eps"]
     assert rel_err(ssq.cpu(), (ref * ref).sum((0, 2, 3))) < 1e-4
     assert (ssum.cpu() - ref.sum((0, 2, 3))).abs().max() < 1e-3 * (ref.abs().sum((0, 2, 3)).max() + 1)
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_dgrad(shape, conv_path):
+def test_conv3x3_bf16_dgrad(shape, conv_path, lowp):
     B, C0, C1, Cout, H, W, _ = shape
     lib = _lib.load()
     g = torch.Generator().manual_seed(1)
     dy = torch.randn(B, Cout, H, W, generator=g)
     w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 3.0
     ref = torch.nn.grad.conv2d_input((B, C0 + C1, H, W), bf(w), bf(dy), padding=1)
-    dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV, dtype=torch.bfloat16)
-    dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV, dtype=torch.bfloat16) if C1 else None
+    dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV, dtype=_cur["dt"])
+    dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV, dtype=_cur["dt"]) if C1 else None
     ddy, dw_ = nhwc_bf(dy), w.to(DEV)
-    check(lib.fu_op_conv3x3_dgrad(BF16, ptr(ddy), Cout, ptr(dw_), ptr(dx0), C0, ptr(dx1), C1, B, H, W, stream()))
+    check(lib.fu_op_conv3x3_dgrad(_cur["code"], ptr(ddy), Cout, ptr(dw_), ptr(dx0), C0, ptr(dx1), C1, B, H, W, stream()))
     torch.cuda.synchronize()
     got = nchw_bf(dx0) if dx1 is None else torch.cat([nchw_bf(dx0), nchw_bf(dx1)], 1)
-    assert rel_err(got, ref) < 4e-3
+    assert rel_err(got, ref) < _cur["eps"]
 
 
 @pytest.fixture(params=["auto", "lockstep"])
@@ -259,7 +273,7 @@ def wgrad_path(request):
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64, 40, 24, True), (1, 96, 0, 32, 16, 16, False),
                                    (16, 128, 0, 128, 32, 32, True), (3, 256, 0, 72, 19, 50, True),
                                    (1, 128, 128, 64, 8, 16, True)])
-def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape):
+def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape, lowp):
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=5)
@@ -272,7 +286,7 @@ def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape):
         lib.fu_test_force_lockstep_wgrad(lock)
         dw = torch.full(w.shape, float("nan"), device=DEV)
         try:
-            check(lib.fu_op_conv3x3_wgrad(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw),
+            check(lib.fu_op_conv3x3_wgrad(_cur["code"], ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw),
                                           B, H, W, stream()))
             torch.cuda.synchronize()
         finally:
@@ -283,7 +297,7 @@ def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape):
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)
-def test_conv3x3_bf16_wgrad(shape, wgrad_path):
+def test_conv3x3_bf16_wgrad(shape, wgrad_path, lowp):
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=2)
@@ -297,13 +311,13 @@ def test_conv3x3_bf16_wgrad(shape, wgrad_path):
     dw = torch.full(w.shape, float("nan"), device=DEV)
     d0, d1, ddy = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None), nhwc_bf(dy)
     da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
-    check(lib.fu_op_conv3x3_wgrad(BF16, ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw), B, H, W,
+    check(lib.fu_op_conv3x3_wgrad(_cur["code"], ptr(d0), C0, ptr(da), ptr(db), ptr(d1), C1, ptr(ddy), Cout, ptr(dw), B, H, W,
                                   stream()))
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), ref) < 1e-4   # exact products of bf16 operands, fp32 accumulation
 
 
-def test_bf16_memory_bound_ops():
+def test_bf16_memory_bound_ops(lowp):
     lib = _lib.load()
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 16, 20, 22, generator=g)
@@ -312,15 +326,15 @@ def test_bf16_memory_bound_ops():
     xr = bf(x)
     z = torch.relu(xr * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
     dx, da, db = nhwc_bf(x), a.to(DEV), b.to(DEV)
-    out = torch.empty(2, 10, 11, 16, device=DEV, dtype=torch.bfloat16)
-    check(lib.fu_op_maxpool2(BF16, ptr(dx), ptr(da), ptr(db), ptr(out), 2, 20, 22, 16, stream()))
-    up = torch.empty(2, 41, 45, 16, device=DEV, dtype=torch.bfloat16)
-    check(lib.fu_op_upsample2(BF16, ptr(dx), ptr(da), ptr(db), ptr(up), 2, 20, 22, 16, 41, 45, stream()))
+    out = torch.empty(2, 10, 11, 16, device=DEV, dtype=_cur["dt"])
+    check(lib.fu_op_maxpool2(_cur["code"], ptr(dx), ptr(da), ptr(db), ptr(out), 2, 20, 22, 16, stream()))
+    up = torch.empty(2, 41, 45, 16, device=DEV, dtype=_cur["dt"])
+    check(lib.fu_op_upsample2(_cur["code"], ptr(dx), ptr(da), ptr(db), ptr(up), 2, 20, 22, 16, 41, 45, stream()))
     torch.cuda.synchronize()
-    assert rel_err(nchw_bf(out), F.max_pool2d(z, 2)) < 3e-3
+    assert rel_err(nchw_bf(out), F.max_pool2d(z, 2)) < _cur["eps"]
     u = F.interpolate(z, scale_factor=2, mode="bilinear", align_corners=True)
     ref = F.pad(u, [0, 1, 0, 1])
-    assert rel_err(nchw_bf(up), ref) < 3e-3
+    assert rel_err(nchw_bf(up), ref) < _cur["eps"]
 
 
 def test_gpu_augmentation_matches_oracle_and_flip_identities():
