@@ -1637,7 +1637,7 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     const float gi = g[i] * gscale;
     float mi = m[i], vi = v[i];
     const float dm = gi - mi;
-    mi = mi + w1 * dm;                        // exp_avg.lerp_(grad, 1-beta1)      (weight < 0.5 branch of ATen's lerp)
+    mi = fmaf(w1, dm, mi);                    // exp_avg.lerp_(grad, 1-beta1): the weight < 0.5 branch of ATen's vectorised lerp, fmadd(weight, end - self, self)
     const float vb = vi * beta2;
     const float og = omb2 * gi;
     vi = vb + og * gi;                        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
