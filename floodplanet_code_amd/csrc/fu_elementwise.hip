@@ -217,10 +217,97 @@ __global__ __launch_bounds__(256) void k_bn_finalize(
   if (nbt && c == 0) *nbt += 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch per BatchNorm instead of two (k_partials_reduce + finalize): per-CHANNEL parallelism.  Channels are
+// independent, so a block that owns 4 channels can reduce ALL their tile partials ([nPart][C][2] fp32, 32 contiguous
+// bytes per tile and block) and finalise them itself -- no second level across blocks, no inter-block hand-off.  128 tile
+// lanes x 2 float4 columns; fp64 accumulation; lanes meet in LDS and are summed in a fixed order (deterministic).
+// MODE 0: forward statistics -> mean / invstd / a / b (+ running statistics); MODE 1: backward sums -> dgamma / dbeta / coef.
+// (The exact data-parallel mode exchanges the partials between the two levels and keeps the two-launch form.)
+// ------------------------------------------------------------------------------------------------
+struct BnFwdOut {
+  const float* conv_bias; const float* gamma; const float* beta; float eps, momentum;
+  float *mean, *invstd, *a, *b, *rmean, *rvar; int64_t* nbt;
+};
+struct BnBwdOut { const float* unscale; float *dgamma, *dbeta, *coef; };
+
+template <int MODE, typename OUT>
+__global__ __launch_bounds__(256) void k_bn_stats_fused(const float* __restrict__ part, int nPart, int C, double count,
+                                                        OUT o) {
+  __shared__ double sm[128][8];
+  const int col = threadIdx.x & 1, tl = threadIdx.x >> 1;
+  const int c0 = blockIdx.x * 4;                        // C % 4 == 0
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const float* base = part + (size_t)c0 * 2 + col * 4;
+  int t = tl;
+  for (; t + 3 * 128 < nPart; t += 4 * 128) {           // four independent 16-byte loads in flight per thread
+    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)t * C * 2);
+    const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(t + 128) * C * 2);
+    const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(t + 256) * C * 2);
+    const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(t + 384) * C * 2);
+    a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+    a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+    a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+  }
+  for (; t < nPart; t += 128) {
+    const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)t * C * 2);
+    a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
+  }
+  sm[tl][col * 4 + 0] = a0; sm[tl][col * 4 + 1] = a1; sm[tl][col * 4 + 2] = a2; sm[tl][col * 4 + 3] = a3;
+  __syncthreads();
+  // 8 values (4 channels x 2) x 16 lanes each: lane j sums tile lanes j, j+16, ... (8 adds), then a fixed xor tree
+  const int v = threadIdx.x >> 4, j = threadIdx.x & 15;
+  double s = 0.0;
+  if (v < 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sm[j + 16 * k][v];
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __syncthreads();
+  if (v < 8 && j == 0) sm[0][v] = s;
+  __syncthreads();
+  if (threadIdx.x >= 4) return;
+  const int c = c0 + threadIdx.x;
+  const double S = sm[0][threadIdx.x * 2 + 0], Q = sm[0][threadIdx.x * 2 + 1];
+  if constexpr (MODE == 0) {
+    const double m0 = S / count;
+    double var = Q / count - m0 * m0;
+    if (var < 0.0) var = 0.0;
+    const double mean = m0 + (o.conv_bias ? (double)o.conv_bias[c] : 0.0);
+    const float invstd = (float)(1.0 / sqrt(var + (double)o.eps));
+    const float meanf = (float)mean;
+    const float a = o.gamma[c] * invstd;
+    o.mean[c] = meanf;
+    o.invstd[c] = invstd;
+    o.a[c] = a;
+    o.b[c] = o.beta[c] - meanf * a;
+    if (o.rmean) {
+      const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      o.rmean[c] = (1.f - o.momentum) * o.rmean[c] + o.momentum * meanf;
+      o.rvar[c] = (1.f - o.momentum) * o.rvar[c] + o.momentum * (float)unbiased;
+    }
+    if (o.nbt && c == 0) *o.nbt += 1;
+  } else {
+    const double us = o.unscale ? (double)*o.unscale : 1.0;
+    if (o.dbeta) o.dbeta[c] = (float)(S * us);
+    if (o.dgamma) o.dgamma[c] = (float)(Q * us);
+    o.coef[c * 2 + 0] = (float)(S / count);
+    o.coef[c * 2 + 1] = (float)(Q / count);
+  }
+}
+
 int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, const float* conv_bias,
                        const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
                        float* a, float* b, float* running_mean, float* running_var, int64_t* nbt, double* dscratch,
                        hipStream_t s) {
+  if (sync_world() <= 1 && C % 4 == 0) {
+    BnFwdOut o{conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt};
+    hipLaunchKernelGGL((k_bn_stats_fused<0, BnFwdOut>), dim3(C / 4), dim3(256), 0, s, partials, nTiles, C, (double)count, o);
+    FU_LAUNCH_CHECK();
+    return 0;
+  }
   int G = 0;
   FU_TRY(reduce_partials<2>(partials, dscratch, nTiles, C, s, &G));
   FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global batch statistics
@@ -402,12 +489,18 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     hipLaunchKernelGGL(k_bn_bwd_reduce<f16_t>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const f16_t*)g,
                        (const f16_t*)y, C, npix, a, b, mean, invstd, partials);
   FU_LAUNCH_CHECK();
-  int G = 0;
-  FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
-  FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global sums of g and g*xhat
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
-                     (double)npix * sync_world(), 1.0 / sync_world(), g_grad_unscale, dgamma, dbeta, coef);
-  FU_LAUNCH_CHECK();
+  if (sync_world() <= 1) {
+    BnBwdOut o{g_grad_unscale, dgamma, dbeta, coef};
+    hipLaunchKernelGGL((k_bn_stats_fused<1, BnBwdOut>), dim3(C / 4), dim3(256), 0, s, partials, nb, C, (double)npix, o);
+    FU_LAUNCH_CHECK();
+  } else {
+    int G = 0;
+    FU_TRY(reduce_partials<2>(partials, dscratch, nb, C, s, &G));
+    FU_TRY(sync_sum_over_ranks(dscratch, (int64_t)G * C * 2, true, s));     // exact DP: global sums of g and g*xhat
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
+                       (double)npix * sync_world(), 1.0 / sync_world(), g_grad_unscale, dgamma, dbeta, coef);
+    FU_LAUNCH_CHECK();
+  }
   const size_t sh2 = (size_t)rows * C * sizeof(float);
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(nb), dim3(BNB_THREADS), sh2, s, (float*)g, (const float*)y, C, npix,

@@ -17,37 +17,48 @@ def _make(rank_seed):
     return O.make_batch(2, 8, 64, 64, seed=20 + rank_seed, n_label_values=2)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: both ranks share GPU 0 (the one-GPU test box; serial backward chain).  nccl: one GPU per rank over RCCL -- the
+    # mode 8 ranks run: side-stream weight gradients joined once per all-reduce bucket (fu_set_side_stream mode 2)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from floodplanet_code_amd.distributed import DataParallelTrainer
     from floodplanet_code_amd.unet import HipUNet
     from oracle import unet_oracle as O
-    dev = torch.device("cuda:0")
     st = O.make_state(8, 3, 16, True, seed=rank)          # ranks start DIFFERENT: the trainer must broadcast rank 0's
     net = HipUNet(8, 3, base_channels=16)
     net.load_state_dict(st)
     net.to(dev).train()
     tr = DataParallelTrainer(net, lr=1e-3, world_size=world, rank=rank, cap_bytes=256 << 10)  # several buckets
+    assert tr._side_mode() == (2 if backend == "nccl" else 0)
     b = _make(rank)
     for _ in range(3):
         tr.step(b["image"].to(dev), b["target"].to(dev), 0)
     torch.cuda.synchronize()
-    flat = net.flat_parameters().cpu()
+    flat = net.flat_parameters() if backend == "nccl" else net.flat_parameters().cpu()
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        torch.save({"p0": gathered[0], "p1": gathered[1]}, out_path)
+        torch.save({"p0": gathered[0].cpu(), "p1": gathered[1].cpu()}, out_path)
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_matches_single_process_average(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_data_parallel_matches_single_process_average(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with two ranks needs two GPUs (the one-GPU test box rehearses the path over gloo)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, backend), nprocs=2, join=True)
     res = torch.load(out)
     assert torch.equal(res["p0"], res["p1"])              # replicas stay bit-identical
 

@@ -139,6 +139,37 @@ def test_training_step_matches_reference_fixture(name):
     assert np.abs(ev.cpu().numpy() - z["eval_logits"]).max() <= 2e-2
 
 
+@pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c4_96_b6"])
+def test_large_batch_full_width_gradients_within_1e3_of_reference(name):
+    """The two larger-batch full-width fixtures (128 / 216 samples per BatchNorm channel at the deepest level): rounding is
+    not amplified and near-ties are rare, so EVERY live gradient tensor is held to 1e-3 of the reference's (norm, and the
+    stored 64-element slice) -- the tight version of the flip-tolerant 3e-2 bound the small-batch fixtures need."""
+    meta, z = load_golden(name)
+    batch, st = case_inputs(meta)
+    net = build(meta, st).train()
+    x, tgt = O.assemble_input(batch, False).to(DEV), batch["target"].to(DEV)
+    loss, logits = net.loss(x, tgt, meta["resolved_ignore_index"], return_logits=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.abs(logits.detach().cpu().numpy() - z["logits1"]).max() <= LOGIT_TOL
+    assert abs(loss.item() - z["loss1"].item()) <= 1e-5
+    worst = 0.0
+    for j, (k, p) in enumerate(net.named_parameters()):
+        if is_dead_bias(k):
+            continue
+        s = z["grad_stats1"][j]
+        if s[2] < 1e-6:
+            continue
+        g = p.grad.detach().cpu().double()
+        assert abs(g.norm().item() - s[2]) <= 1e-3 * s[2], (k, g.norm().item(), s[2])
+        ref = torch.from_numpy(z[f"g1s_{j}"] if f"g1s_{j}" in z.files else z[f"g1_{j}"].reshape(-1)[:64]).double()
+        scale = max(ref.norm().item(), s[2] * (64 / max(64, g.numel())) ** 0.5)
+        d = (g.reshape(-1)[:ref.numel()] - ref).norm().item() / scale
+        worst = max(worst, d)
+        assert d <= 1e-3, (k, d)
+    print(f"{name}: worst gradient slice error {worst:.2e}")
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 64, 64, 16), (1, 5, 50, 38, 8), (2, 8, 64, 64, 64)])
 def test_matches_live_oracle(shape):
     """Same seeded inputs through the oracle on the host CPU (fp32 AND fp64) and through the HIP path:
