@@ -17,7 +17,9 @@ gradients must be within max(3x the torch-fp32 error, 1e-2) of the fp64 truth.  
 excluded from elementwise checks: their gradient is analytically zero (conftest.is_dead_bias).
 """
 GRAD_TOL = 3e-2        # per tensor (flip-dominated, see above)
-GRAD_MEDIAN_TOL = 5e-3  # median of the per-tensor relative errors of one backward pass
+GRAD_MEDIAN_TOL = 8e-3  # median of the per-tensor relative errors of one backward pass (5e-3 until the two larger-batch
+                        # full-width fixtures were added: on f_full_c4_96_b6 torch-fp32 ITSELF sits 6.2e-3 (median) from an
+                        # fp64 run, the HIP path 2.2e-3, hence 6.6e-3 between the two -- tools/grad_truth_diag.py)
 import numpy as np
 import pytest
 import torch
@@ -140,34 +142,38 @@ def test_training_step_matches_reference_fixture(name):
 
 
 @pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c4_96_b6"])
-def test_large_batch_full_width_gradients_within_1e3_of_reference(name):
-    """The two larger-batch full-width fixtures (128 / 216 samples per BatchNorm channel at the deepest level): rounding is
-    not amplified and near-ties are rare, so EVERY live gradient tensor is held to 1e-3 of the reference's (norm, and the
-    stored 64-element slice) -- the tight version of the flip-tolerant 3e-2 bound the small-batch fixtures need."""
+def test_large_batch_full_width_gradients_against_fp64_truth(name):
+    """The two larger-batch full-width fixtures (B=8 at 64x64, B=6 at 96x96: 128 / 216 samples per BatchNorm channel at the
+    deepest level).  MEASURED (tools/grad_truth_diag.py): a larger batch does NOT make fp32 gradients of this net 1e-3-exact
+    -- the reference's own torch-fp32 gradients are 5.2e-3 / 6.2e-3 (median rel-L2 per tensor) from an fp64 run of the same
+    graph, the HIP path 6.1e-3 / 2.2e-3.  So the honest tight statement is against the fp64 truth: the HIP gradients must be
+    as close to it as the reference arithmetic is (median <= 1.5x, worst tensor <= 2x), and logits / loss exact as ever."""
     meta, z = load_golden(name)
     batch, st = case_inputs(meta)
+    ii = meta["resolved_ignore_index"]
     net = build(meta, st).train()
     x, tgt = O.assemble_input(batch, False).to(DEV), batch["target"].to(DEV)
-    loss, logits = net.loss(x, tgt, meta["resolved_ignore_index"], return_logits=True)
+    loss, logits = net.loss(x, tgt, ii, return_logits=True)
     loss.backward()
     torch.cuda.synchronize()
     assert np.abs(logits.detach().cpu().numpy() - z["logits1"]).max() <= LOGIT_TOL
     assert abs(loss.item() - z["loss1"].item()) <= 1e-5
-    worst = 0.0
-    for j, (k, p) in enumerate(net.named_parameters()):
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    _, _, g32 = O.loss_and_grads({k: v.clone() for k, v in st.items()}, batch, ii)
+    st64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in st.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    _, _, g64 = O.loss_and_grads(st64, b64, ii)
+    e_hip, e_ref = [], []
+    for k, p in net.named_parameters():
         if is_dead_bias(k):
             continue
-        s = z["grad_stats1"][j]
-        if s[2] < 1e-6:
-            continue
-        g = p.grad.detach().cpu().double()
-        assert abs(g.norm().item() - s[2]) <= 1e-3 * s[2], (k, g.norm().item(), s[2])
-        ref = torch.from_numpy(z[f"g1s_{j}"] if f"g1s_{j}" in z.files else z[f"g1_{j}"].reshape(-1)[:64]).double()
-        scale = max(ref.norm().item(), s[2] * (64 / max(64, g.numel())) ** 0.5)
-        d = (g.reshape(-1)[:ref.numel()] - ref).norm().item() / scale
-        worst = max(worst, d)
-        assert d <= 1e-3, (k, d)
-    print(f"{name}: worst gradient slice error {worst:.2e}")
+        n64 = g64[k].norm().item() + 1e-30
+        e_hip.append((p.grad.cpu().double() - g64[k]).norm().item() / n64)
+        e_ref.append((g32[k].double() - g64[k]).norm().item() / n64)
+    print(f"{name}: HIP vs fp64 median {np.median(e_hip):.2e} max {max(e_hip):.2e}; torch-fp32 vs fp64 median "
+          f"{np.median(e_ref):.2e} max {max(e_ref):.2e}")
+    assert np.median(e_hip) <= max(1.5 * np.median(e_ref), 2e-3), (np.median(e_hip), np.median(e_ref))
+    assert max(e_hip) <= max(2.0 * max(e_ref), 5e-3), (max(e_hip), max(e_ref))
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 64, 64, 16), (1, 5, 50, 38, 8), (2, 8, 64, 64, 64)])
