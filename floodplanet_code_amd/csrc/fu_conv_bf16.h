@@ -27,6 +27,8 @@
 #define k_conv3x3_bf16_fast k_conv3x3_f16_fast
 #define k_wgrad_bf16 k_wgrad_f16
 #define k_wgrad_bf16_pp k_wgrad_f16_pp
+#define conv3x3_rs_eligible conv3x3_rs_eligible_f16
+#define launch_conv3x3_rs launch_conv3x3_rs_f16
 #endif
 
 #include <type_traits>
@@ -121,6 +123,9 @@ struct BConvP {
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
 bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
+// row-stationary 16x16x32 kernel (fu_conv_rs.hip)
+bool conv3x3_rs_eligible(const BConvP& P);
+int launch_conv3x3_rs(BConvP& P, hipStream_t s);
 
 }  // namespace fu
 

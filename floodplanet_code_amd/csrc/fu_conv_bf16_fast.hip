@@ -569,6 +569,14 @@ int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
   const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
   const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
   if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, s) : launch_fast_cfg<1, 1>(P, s);
+  // Row-stationary kernel (fu_conv_rs.hip), wherever the shape is eligible and one of its tiles gives every CU two
+  // workgroups.  Measured per layer against the kernels below (bench shapes, forward, tools/conv_modes.py): 5-11 % faster
+  // on the 128x128, 64x64 and 32x32 layers with N >= 512 channels x tiles, equal on the two-chunk 256x256 layers, slower
+  // below 512 workgroups (16x16 level, 512 -> 256 at 32x32).  Tile mode 3 forces it, modes 1 / 2 exclude it.
+  if (conv3x3_rs_eligible(P)) {
+    const int64_t t256 = (int64_t)P.B * (P.H / 16) * (P.W / 16) * (P.N / 64);
+    if (g_bf16_tile_mode == 3 || (g_bf16_tile_mode == 0 && t256 >= 512)) return launch_conv3x3_rs(P, s);
+  }
   // tall tile (16 x 32 pixels, 16-channel chunks).  Measured per layer against the square tile (bench shapes, one
   // stream): 5-9 % faster where it still yields >= 2048 workgroups (the 256x256 layers; the 8-channel first conv 60 ->
   // 46 us), within +-4 % at 1024, 10 % slower at <= 512 -- hence the threshold.

@@ -176,6 +176,13 @@ BF_SHAPES = [
     (1, 96, 0, 32, 16, 16, False),   # one tile, narrow (32-channel) workgroups
     (2, 128, 64, 64, 40, 24, True),  # second destination at a 64-channel boundary (dgrad: D0 = 128)
     (4, 32, 0, 64, 208, 200, True),  # >= 512 64-channel tiles with ragged rows AND columns: the tall 16x32 tile's masked epilogue
+    # shapes the row-stationary kernel takes (Cin % 32 == 0, N % 64 == 0, H % 32 == 0, W % 16 == 0): border + interior tiles,
+    # two sources, two destinations (dgrad), several channel tiles, one and many K chunks
+    (2, 64, 0, 64, 64, 48, True),
+    (1, 64, 64, 128, 96, 32, True),
+    (2, 128, 64, 64, 32, 16, True),
+    (1, 256, 0, 192, 32, 32, False),
+    (3, 32, 0, 64, 160, 80, True),
 ]
 
 
@@ -205,13 +212,13 @@ def nchw_bf(x):
     return x.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
-@pytest.fixture(params=["auto", "general", "tall", "square"])
+@pytest.fixture(params=["auto", "general", "tall", "square", "rs"])
 def conv_path(request):
     """bf16 forward/dgrad have an aligned-shape fast kernel (16x16 and tall 16x32 workgroup tiles) and a general one:
     run every shape on all of them."""
     lib = _lib.load()
     lib.fu_test_force_general_conv(1 if request.param == "general" else 0)
-    lib.fu_test_conv_tile_mode({"tall": 2, "square": 1}.get(request.param, 0))
+    lib.fu_test_conv_tile_mode({"tall": 2, "square": 1, "rs": 3}.get(request.param, 0))
     yield request.param
     lib.fu_test_force_general_conv(0)
     lib.fu_test_conv_tile_mode(0)
