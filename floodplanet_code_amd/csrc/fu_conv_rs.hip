@@ -75,10 +75,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
 
   // ---- activation staging slots: unit u = tid + 256 it = halo pixel (tid >> 2) + 64 it, channel octet tid & 3
   const int aq = tid & 3, srow = tid >> 2;
-  unsigned a_off[A_ITERS];
+  unsigned a_pix[A_ITERS];                                         // clamped pixel index of the slot (< 2^24: eligibility)
   unsigned a_ok = 0, a_swz = 0;                                    // bit it: pixel inside the image / LDS slot swizzled
-  auto setup_a = [&](int Cs) {
-    a_ok = 0; a_swz = 0;
+  {
     static_for<0, A_ITERS>([&](auto I) {
       constexpr int it = decltype(I)::value;
       const int hp = srow + it * 64;
@@ -89,10 +88,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
       const bool ok = (it < Cfg::A_FULL || hp < NHP) && iy == cy && ix == cx;
       a_ok |= ok ? (1u << it) : 0u;
       a_swz |= (hx & 4) ? (1u << it) : 0u;
-      a_off[it] = (unsigned)((bb * P.H + cy) * P.W + cx) * (unsigned)(Cs * 2) + 16u * aq;
+      a_pix[it] = (unsigned)((bb * P.H + cy) * P.W + cx);
     });
-  };
-  setup_a(P.C0);
+  }
 
   // ---- weight DMA: instruction `tap` of wave wm fills LDS rows [tap*64 + 16 wm, +16) = subtile s = wm of that tap.
   //      Lane i lands on row m = i >> 2, physical slot i & 3, i.e. k-group g = (i & 3) ^ ((m & 4) >> 1); row m of subtile s
@@ -113,14 +111,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
 
   uint4 ra[A_ITERS];
   const char* abL = nullptr;
+  unsigned cs2 = 0;                                                // bytes per pixel of the current source (uniform)
   auto load_begin = [&](int k0) {
     const bool s1 = P.src1 != nullptr && k0 >= P.C0;               // uniform
     abL = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
              : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
+    cs2 = (unsigned)(s1 ? P.C1 : P.C0) * 2u;
   };
   auto load_slot = [&](auto Sc) {
     constexpr int sl = decltype(Sc)::value;
-    if constexpr (sl < A_ITERS) ra[sl] = *reinterpret_cast<const uint4*>(abL + a_off[sl]);
+    // uniform base + 32-bit lane offset = pixel * (channels * 2) + 16 aq: one v_mad_u32_u24 per load (pixel < 2^24,
+    // bytes per pixel < 2^24; the product < 2^31 by eligibility)
+    if constexpr (sl < A_ITERS)
+      ra[sl] = *reinterpret_cast<const uint4*>(abL + ((a_pix[sl] & 0xffffffu) * (cs2 & 0xffffffu) + 16u * aq));
   };
 
   // LDS address of slot it: row (srow + 64 it), byte (16 aq) ^ (32 if the pixel's column has bit 2 set): the two candidate
@@ -238,7 +241,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   for (int ch = 0; ch + 1 < nChunks; ++ch) {
     const int k0 = ch * KC;
     stage(k0, ch == 0);
-    if (P.src1 != nullptr && k0 + KC == P.C0) setup_a(P.C1);   // the next chunk starts the second source
     load_begin(k0 + KC);
     mfma_block(std::true_type{});
   }
@@ -273,17 +275,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   }
   if (P.stats) {
     // per-channel sums over the tile: 16 lanes (pixels) of a row group, then the 4 waves through LDS; fixed order
+    // DPP only (a __shfl_xor is a ds_bpermute: 128 of them were ~4000 cycles of a 2-chunk tile): row_shr 1, 2, 4, 8
+    // inside the 16-lane rows; lane 15 of every row ends with the row's total
+    auto row_sum = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+      return v;
+    };
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        ssum[c] += __shfl_xor(ssum[c], off, 64);
-        ssq[c] += __shfl_xor(ssq[c], off, 64);
-      }
-    }
+    for (int c = 0; c < 16; ++c) { ssum[c] = row_sum(ssum[c]); ssq[c] = row_sum(ssq[c]); }
     float* red = reinterpret_cast<float*>(smem_raw);            // [4 waves][64 channels][2]
     __syncthreads();
-    if (lx == 0) {
+    if (lx == 15) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         red[(wm * BN + 16 * lg + c) * 2 + 0] = ssum[c];
@@ -311,7 +316,7 @@ bool conv3x3_rs_eligible(const BConvP& P) {
   if (P.dst1 && (P.D0 % 64) != 0) return false;
   if (P.a0 != nullptr && P.C0 > 512) return false;
   if (px * P.C0 * 2 >= lim || px * P.C1 * 2 >= lim || px * P.D0 * 2 >= lim || px * P.D1 * 2 >= lim) return false;
-  if ((int64_t)9 * P.N * P.Cin * 2 >= lim) return false;
+  if ((int64_t)9 * P.N * P.Cin * 2 >= lim || px >= ((int64_t)1 << 24)) return false;
   return true;
 }
 
