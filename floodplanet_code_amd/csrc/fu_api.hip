@@ -208,12 +208,14 @@ struct Block {
   void* up = nullptr;         // BK_UP: upsampled + padded low-resolution input
   void* g_up = nullptr;
   UpTables upt;
-  // bilinear=False: ConvTranspose2d(ct_cin, ct_cout, 2, 2) run as a 3x3 conv over the zero-stuffed input
+  // bilinear=False: ConvTranspose2d(ct_cin, ct_cout, 2, 2) = one 1x1 conv ct_cin -> 4 ct_cout (phase-major) at the low
+  // resolution + depth-to-space
   int ct_w = -1, ct_b = -1, ct_cin = 0, ct_cout = 0;
-  void* u = nullptr;          // zero-stuffed relu(bn(low)) at this block's resolution, ct_cin channels
-  void* g_u = nullptr;
-  float* ct_w3 = nullptr;     // embedded OIHW 3x3 weight [ct_cout][ct_cin][3][3] (fp32)
+  void* u = nullptr;          // y4: the 1x1 conv's output [B, h, w, 4 ct_cout]
+  void* g_u = nullptr;        // g4: its gradient (space-to-depth of dL/d up)
+  float* ct_w3 = nullptr;     // embedded OIHW weight [4 ct_cout][ct_cin][3][3] (fp32, centre tap only)
   float* ct_dw3 = nullptr;    // its gradient
+  float* ct_b4 = nullptr;     // bias repeated per phase [4 ct_cout]
   void* ct_wf = nullptr;      // packed forward / dgrad copies
   void* ct_wd = nullptr;
   int first_param = 0, num_params = 0;  // contiguous range in the canonical parameter table
@@ -520,13 +522,14 @@ int alloc_workspace(fu_ctx* c) {
       A.want(&K.g_up, act(K.level, clow));
       if (!f.bilinear) {
         const int H = c->Hs[K.level], W = c->Ws[K.level];
-        A.want(&K.u, act(K.level, K.ct_cin));
-        A.want(&K.g_u, act(K.level, K.ct_cin));
-        A.want(&K.ct_w3, (size_t)9 * K.ct_cin * K.ct_cout * sizeof(float));
-        A.want(&K.ct_dw3, (size_t)9 * K.ct_cin * K.ct_cout * sizeof(float));
-        A.want(&K.ct_wf, conv3x3_pack_elems(c->prec, K.ct_cin, K.ct_cout) * es);
-        A.want(&K.ct_wd, conv3x3_pack_elems(c->prec, K.ct_cin, K.ct_cout) * es);
-        max_slab = std::max<int64_t>(max_slab, conv3x3_wgrad_slab_elems(c->prec, K.ct_cin, K.ct_cout, B, H, W));
+        A.want(&K.u, act(K.level, K.ct_cout));            // = B h w (4 ct_cout)
+        A.want(&K.g_u, act(K.level, K.ct_cout));
+        A.want(&K.ct_w3, (size_t)9 * K.ct_cin * 4 * K.ct_cout * sizeof(float));
+        A.want(&K.ct_dw3, (size_t)9 * K.ct_cin * 4 * K.ct_cout * sizeof(float));
+        A.want(&K.ct_b4, (size_t)4 * K.ct_cout * sizeof(float));
+        A.want(&K.ct_wf, conv3x3_pack_elems(c->prec, K.ct_cin, 4 * K.ct_cout) * es);
+        A.want(&K.ct_wd, conv3x3_pack_elems(c->prec, K.ct_cin, 4 * K.ct_cout) * es);
+        max_slab = std::max<int64_t>(max_slab, conv3x3_wgrad_slab_elems(c->prec, K.ct_cin, 4 * K.ct_cout, B, H / 2, W / 2));
         max_dbp = std::max<int64_t>(max_dbp, (int64_t)2048 * K.ct_cout);
       }
     }
@@ -640,8 +643,8 @@ int repack(fu_ctx* c, hipStream_t s) {
   if (!c->cfg.bilinear) {
     for (int i = 5 * c->nE; i < c->nb; ++i) {
       Block& K = c->blk[i];
-      FU_TRY(launch_convT_to_w3(P(c, K.ct_w), K.ct_cin, K.ct_cout, K.ct_w3, s));
-      FU_TRY(launch_pack_conv3x3(c->prec, K.ct_w3, K.ct_cout, K.ct_cin, K.ct_cin, K.ct_wf, K.ct_wd, s));
+      FU_TRY(launch_convT_to_w3(P(c, K.ct_w), P(c, K.ct_b), K.ct_cin, K.ct_cout, K.ct_w3, K.ct_b4, s));
+      FU_TRY(launch_pack_conv3x3(c->prec, K.ct_w3, 4 * K.ct_cout, K.ct_cin, K.ct_cin, K.ct_wf, K.ct_wd, s));
     }
   }
   c->packed_dirty = false;
@@ -761,12 +764,11 @@ int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_
       if (c->cfg.bilinear) {
         FU_TRY(launch_upsample2(c->prec, pv.y, pv.a, pv.b, K.up, B, h, w, pv.C, H, W, K.upt, s));
       } else {
-        // ConvTranspose2d(k2,s2) (unet.py:48-51) = 3x3 conv of the zero-stuffed input, then F.pad (unet.py:57-62)
-        FU_TRY(launch_zero_stuff(c->prec, pv.y, pv.a, pv.b, K.u, B, h, w, K.ct_cin, H, W, s));
-        ConvIn uin{K.u, K.ct_cin, nullptr, nullptr, nullptr, 0};
-        FU_TRY(launch_conv3x3(c->prec, uin, K.ct_wf, P(c, K.ct_b), K.up, K.ct_cout, nullptr, 0, nullptr, nullptr, B, H,
-                              W, s));
-        FU_TRY(launch_zero_border(c->prec, K.up, B, h, w, K.ct_cout, H, W, s));
+        // ConvTranspose2d(k2,s2) (unet.py:48-51): the four phase GEMMs as one 1x1 conv of relu(bn(low)) with 4 ct_cout
+        // output channels at the low resolution, then depth-to-space + F.pad (unet.py:57-62)
+        ConvIn lin{pv.y, pv.C, pv.a, pv.b, nullptr, 0, true};
+        FU_TRY(launch_conv3x3(c->prec, lin, K.ct_wf, K.ct_b4, K.u, 4 * K.ct_cout, nullptr, 0, nullptr, nullptr, B, h, w, s));
+        FU_TRY(launch_depth_to_space(c->prec, K.u, K.up, B, h, w, K.ct_cout, H, W, s));
       }
     }
     FU_TRY(conv_fwd(c, i, 0, B, training, s));
@@ -839,16 +841,19 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     if (c->cfg.bilinear) {
       FU_TRY(launch_upsample2_bwd(c->prec, K.g_up, pv.gy, B, h, w, pv.C, H, W, K.upt, s));
     } else {
-      FU_TRY(launch_zero_border(c->prec, K.g_up, B, h, w, K.ct_cout, H, W, s));      // F.pad region carries no gradient
+      // g4 = space-to-depth of dL/d(up) (the F.pad region carries no gradient: it is simply not gathered); the 1x1 conv's
+      // bias gradient is the sum of g4 over pixels and phases, its weight gradient a one-tap wgrad, its data gradient a
+      // 1x1 conv with the transposed weights
+      FU_TRY(launch_space_to_depth(c->prec, K.g_up, K.g_u, B, h, w, K.ct_cout, H, W, s));
       int ndbp = 0;
-      FU_TRY(launch_channel_partial_sums(c->prec, K.g_up, K.ct_cout, (int64_t)B * H * W, c->db_part, &ndbp, s));
-      ConvIn uin{K.u, K.ct_cin, nullptr, nullptr, nullptr, 0};
-      FU_TRY(launch_conv3x3_wgrad(c->prec, uin, K.g_up, K.ct_cout, c->slab, K.ct_dw3, K.ct_cin, c->db_part, ndbp,
-                                  G(c, K.ct_b), B, H, W, s));
+      FU_TRY(launch_channel_partial_sums(c->prec, K.g_u, K.ct_cout, (int64_t)B * h * w * 4, c->db_part, &ndbp, s));
+      FU_TRY(launch_colsum_partials(c->db_part, ndbp, K.ct_cout, G(c, K.ct_b), s));
+      ConvIn lin{pv.y, pv.C, pv.a, pv.b, nullptr, 0, true};
+      FU_TRY(launch_conv3x3_wgrad(c->prec, lin, K.g_u, 4 * K.ct_cout, c->slab, K.ct_dw3, K.ct_cin, nullptr, 0, nullptr, B, h,
+                                  w, s));
       FU_TRY(launch_convT_grad_from_w3(K.ct_dw3, K.ct_cin, K.ct_cout, G(c, K.ct_w), s));
-      ConvIn gin{K.g_up, K.ct_cout, nullptr, nullptr, nullptr, 0};
-      FU_TRY(launch_conv3x3(c->prec, gin, K.ct_wd, nullptr, K.g_u, K.ct_cin, nullptr, 0, nullptr, nullptr, B, H, W, s));
-      FU_TRY(launch_gather_even(c->prec, K.g_u, pv.gy, B, h, w, K.ct_cin, H, W, s));
+      ConvIn gin{K.g_u, 4 * K.ct_cout, nullptr, nullptr, nullptr, 0, true};
+      FU_TRY(launch_conv3x3(c->prec, gin, K.ct_wd, nullptr, pv.gy, K.ct_cin, nullptr, 0, nullptr, nullptr, B, h, w, s));
     }
   }
   return 0;

@@ -319,16 +319,16 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
 int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
                          const UpTables& t, hipStream_t s);
 
-// ConvTranspose2d(k2,s2) helpers (bilinear=False variant): zero-stuffing, even-position gather, pad-region zeroing,
-// bias-gradient partial sums, weight <-> embedded-3x3 conversions
-int launch_zero_stuff(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
-                      int outH, int outW, hipStream_t s);
-int launch_gather_even(Prec p, const void* gu, void* gsrc, int B, int H, int W, int C, int outH, int outW,
-                       hipStream_t s);
+// ConvTranspose2d(k2,s2) helpers (bilinear=False variant): the four phase GEMMs run as one 1x1 conv with 4 cout channels at
+// the low resolution; depth-to-space (+ F.pad) / space-to-depth (- pad) move between [B,h,w,4C] and [B,2h(+pad),2w(+pad),C];
+// pad-region zeroing, bias-gradient partial sums, weight <-> embedded-centre-tap conversions
+int launch_depth_to_space(Prec p, const void* y4, void* up, int B, int h, int w, int C, int outH, int outW, hipStream_t s);
+int launch_space_to_depth(Prec p, const void* gup, void* g4, int B, int h, int w, int C, int outH, int outW, hipStream_t s);
+int launch_colsum_partials(const float* partials, int n, int C, float* out, hipStream_t s);
 int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, int outW, hipStream_t s);
 int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, float* partials, int* n_partials,
                                 hipStream_t s);
-int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t s);
+int launch_convT_to_w3(const float* w, const float* b, int Cin, int Cout, float* w3, float* bias4, hipStream_t s);
 int launch_convT_grad_from_w3(const float* dw3, int Cin, int Cout, float* dw, hipStream_t s);
 int launch_copy_channels(Prec p, const void* src, int srcC, int src_off, const float* a, const float* b, void* dst,
                          int dstC, int dst_off, int C, int64_t npix, hipStream_t s);

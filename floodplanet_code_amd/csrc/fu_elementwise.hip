@@ -783,14 +783,18 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// ConvTranspose2d(k=2, s=2) support (bilinear=False variant, unet.py:48-51).  The transposed conv is executed as
-// a 3x3 convolution of the zero-stuffed input (u[2y,2x] = x[y,x], zeros elsewhere) with the 2x2 kernel embedded in
-// the top-left taps, so forward / dgrad / wgrad reuse the MFMA conv kernels; these helpers do the data movement.
+// ConvTranspose2d(k=2, s=2) support (bilinear=False variant, unet.py:48-51).  out[2y+ky][2x+kx][co] =
+// sum_ci in[y][x][ci] * w[ci][co][ky][kx] + b[co]: four independent 1x1 GEMMs, one per output phase p = 2 ky + kx.  They
+// run as ONE 1x1 convolution at the LOW resolution with N = 4 cout output channels ordered (p, co) -- on the MFMA conv
+// kernels with the weight embedded as a centre tap, exactly the MACs the operator needs (the first version convolved the
+// zero-stuffed input with a 3x3 kernel: 9/4 of the MACs and three extra passes) -- followed by a depth-to-space pass that
+// interleaves the phases and applies F.pad (unet.py:57-62).  Backward: space-to-depth of dL/d(up) (which crops the pad),
+// then the 1x1 conv's dgrad and its one-tap wgrad.
 // ------------------------------------------------------------------------------------------------
+// up[b][py0 + 2y + ky][px0 + 2x + kx][co] = y4[b][y][x][(2 ky + kx) cout + co]; zero outside the 2h x 2w window
 template <typename T>
-__global__ void k_zero_stuff(const T* __restrict__ src, const float* __restrict__ a, const float* __restrict__ b,
-                             T* __restrict__ dst, int H, int W, int C, int outH, int outW, int py0, int px0,
-                             int64_t total) {
+__global__ void k_depth_to_space(const T* __restrict__ y4, T* __restrict__ up, int h, int w, int C, int outH, int outW,
+                                 int py0, int px0, int64_t total) {
   const int CV = C >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -801,30 +805,29 @@ __global__ void k_zero_stuff(const T* __restrict__ src, const float* __restrict_
     const int64_t bb = r / outH;
     float o[4] = {0, 0, 0, 0};
     const int uy = oy - py0, ux = ox - px0;
-    if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W && !(uy & 1) && !(ux & 1)) {
-      float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-      const bool bn = a != nullptr;
-      if (bn) { ElemIO<float>::load4(a + cv * 4, av); ElemIO<float>::load4(b + cv * 4, bv); }
-      load_act4<T>(src + ((bb * H + (uy >> 1)) * W + (ux >> 1)) * (int64_t)C + cv * 4, av, bv, bn, o);
+    if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+      const int ph = (uy & 1) * 2 + (ux & 1);
+      ElemIO<T>::load4(y4 + (((bb * h + (uy >> 1)) * w + (ux >> 1)) * 4 + ph) * (int64_t)C + cv * 4, o);
     }
-    ElemIO<T>::store4(dst + idx * 4, o);
+    ElemIO<T>::store4(up + idx * 4, o);
   }
 }
-
+// g4[b][y][x][(2 ky + kx) cout + co] = g_up[b][py0 + 2y + ky][px0 + 2x + kx][co]  (the pad region is dropped)
 template <typename T>
-__global__ void k_gather_even(const T* __restrict__ gu, T* __restrict__ gsrc, int H, int W, int C, int outH, int outW,
-                              int py0, int px0, int64_t total) {
+__global__ void k_space_to_depth(const T* __restrict__ gup, T* __restrict__ g4, int h, int w, int C, int outH, int outW,
+                                 int py0, int px0, int64_t total) {
   const int CV = C >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(idx % CV);
     int64_t r = idx / CV;
-    const int ix = (int)(r % W); r /= W;
-    const int iy = (int)(r % H);
-    const int64_t bb = r / H;
+    const int ph = (int)(r & 3); r >>= 2;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int64_t bb = r / h;
     float v[4];
-    ElemIO<T>::load4(gu + ((bb * outH + py0 + 2 * iy) * outW + px0 + 2 * ix) * (int64_t)C + cv * 4, v);
-    ElemIO<T>::store4(gsrc + idx * 4, v);
+    ElemIO<T>::load4(gup + ((bb * outH + py0 + 2 * y + (ph >> 1)) * outW + px0 + 2 * x + (ph & 1)) * (int64_t)C + cv * 4, v);
+    ElemIO<T>::store4(g4 + idx * 4, v);
   }
 }
 
@@ -872,16 +875,19 @@ __global__ void k_channel_partial_sums(const T* __restrict__ g, int C, int64_t n
   }
 }
 
-// convT weight [Cin][Cout][2][2] -> OIHW 3x3 [Cout][Cin][3][3]: w3[a][b] = w[1-a][1-b] for a,b in {0,1}, else 0
-__global__ void k_convT_to_w3(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ w3, int64_t total) {
+// convT weight [Cin][Cout][2][2] -> the embedded 1x1: OIHW 3x3 [(p, co)][Cin][3][3] with w3[...][centre] = w[ci][co][ky][kx]
+// (p = 2 ky + kx), zeros elsewhere; bias4[(p, co)] = b[co]
+__global__ void k_convT_to_w3(const float* __restrict__ w, const float* __restrict__ b, int Cin, int Cout,
+                              float* __restrict__ w3, float* __restrict__ bias4, int64_t total) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int tap = (int)(idx % 9);
     const int64_t r = idx / 9;
     const int ci = (int)(r % Cin);
-    const int co = (int)(r / Cin);
-    const int a = tap / 3, b = tap % 3;
-    w3[idx] = (a < 2 && b < 2) ? w[(((int64_t)ci * Cout + co) * 2 + (1 - a)) * 2 + (1 - b)] : 0.f;
+    const int n4 = (int)(r / Cin);                 // (p, co)
+    const int ph = n4 / Cout, co = n4 - ph * Cout;
+    w3[idx] = tap == 4 ? w[(((int64_t)ci * Cout + co) * 2 + (ph >> 1)) * 2 + (ph & 1)] : 0.f;
+    if (tap == 4 && ci == 0) bias4[n4] = b[co];
   }
 }
 __global__ void k_convT_grad_from_w3(const float* __restrict__ dw3, int Cin, int Cout, float* __restrict__ dw,
@@ -892,41 +898,56 @@ __global__ void k_convT_grad_from_w3(const float* __restrict__ dw3, int Cin, int
     const int64_t r = idx >> 2;
     const int co = (int)(r % Cout);
     const int ci = (int)(r / Cout);
-    dw[idx] = dw3[((int64_t)co * Cin + ci) * 9 + (1 - ky) * 3 + (1 - kx)];
+    dw[idx] = dw3[((int64_t)((ky * 2 + kx) * Cout + co) * Cin + ci) * 9 + 4];
   }
 }
+// out[c] = unscale * sum_i partials[i][c]  (bias gradient of the transposed conv; fixed order)
+__global__ void k_colsum_partials(const float* __restrict__ partials, int n, int C, const float* __restrict__ unscale,
+                                  float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)partials[(int64_t)i * C + c];
+  if (unscale) s *= (double)*unscale;
+  out[c] = (float)s;
+}
 
-int launch_zero_stuff(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
-                      int outH, int outW, hipStream_t s) {
-  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
+int launch_depth_to_space(Prec p, const void* y4, void* up, int B, int h, int w, int C, int outH, int outW,
+                          hipStream_t s) {
+  const int py0 = (outH - 2 * h) / 2, px0 = (outW - 2 * w) / 2;
   const int64_t total = (int64_t)B * outH * outW * (C / 4);
   const int g = grid_for(total, 256);
   if (p == PREC_F32)
-    hipLaunchKernelGGL(k_zero_stuff<float>, dim3(g), dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C,
-                       outH, outW, py0, px0, total);
+    hipLaunchKernelGGL(k_depth_to_space<float>, dim3(g), dim3(256), 0, s, (const float*)y4, (float*)up, h, w, C, outH,
+                       outW, py0, px0, total);
   else if (p == PREC_BF16)
-    hipLaunchKernelGGL(k_zero_stuff<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C,
-                       outH, outW, py0, px0, total);
+    hipLaunchKernelGGL(k_depth_to_space<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)y4, (bf16_t*)up, h, w, C, outH,
+                       outW, py0, px0, total);
   else
-    hipLaunchKernelGGL(k_zero_stuff<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)src, a, b, (f16_t*)dst, H, W, C,
-                       outH, outW, py0, px0, total);
+    hipLaunchKernelGGL(k_depth_to_space<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)y4, (f16_t*)up, h, w, C, outH,
+                       outW, py0, px0, total);
   FU_LAUNCH_CHECK();
   return 0;
 }
-int launch_gather_even(Prec p, const void* gu, void* gsrc, int B, int H, int W, int C, int outH, int outW,
-                       hipStream_t s) {
-  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
-  const int64_t total = (int64_t)B * H * W * (C / 4);
+int launch_space_to_depth(Prec p, const void* gup, void* g4, int B, int h, int w, int C, int outH, int outW,
+                          hipStream_t s) {
+  const int py0 = (outH - 2 * h) / 2, px0 = (outW - 2 * w) / 2;
+  const int64_t total = (int64_t)B * h * w * 4 * (C / 4);
   const int g = grid_for(total, 256);
   if (p == PREC_F32)
-    hipLaunchKernelGGL(k_gather_even<float>, dim3(g), dim3(256), 0, s, (const float*)gu, (float*)gsrc, H, W, C, outH,
+    hipLaunchKernelGGL(k_space_to_depth<float>, dim3(g), dim3(256), 0, s, (const float*)gup, (float*)g4, h, w, C, outH,
                        outW, py0, px0, total);
   else if (p == PREC_BF16)
-    hipLaunchKernelGGL(k_gather_even<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)gsrc, H, W, C, outH,
+    hipLaunchKernelGGL(k_space_to_depth<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)gup, (bf16_t*)g4, h, w, C, outH,
                        outW, py0, px0, total);
   else
-    hipLaunchKernelGGL(k_gather_even<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)gu, (f16_t*)gsrc, H, W, C, outH,
+    hipLaunchKernelGGL(k_space_to_depth<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)gup, (f16_t*)g4, h, w, C, outH,
                        outW, py0, px0, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_colsum_partials(const float* partials, int n, int C, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum_partials, dim3(ceil_div(C, 64)), dim3(64), 0, s, partials, n, C, g_grad_unscale, out);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -968,9 +989,9 @@ int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, floa
   *n_partials = (int)nb;
   return 0;
 }
-int launch_convT_to_w3(const float* w, int Cin, int Cout, float* w3, hipStream_t s) {
-  const int64_t total = (int64_t)Cout * Cin * 9;
-  hipLaunchKernelGGL(k_convT_to_w3, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, w, Cin, Cout, w3, total);
+int launch_convT_to_w3(const float* w, const float* b, int Cin, int Cout, float* w3, float* bias4, hipStream_t s) {
+  const int64_t total = (int64_t)4 * Cout * Cin * 9;
+  hipLaunchKernelGGL(k_convT_to_w3, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, w, b, Cin, Cout, w3, bias4, total);
   FU_LAUNCH_CHECK();
   return 0;
 }
