@@ -1294,6 +1294,15 @@ int fu_augment(const float* image, const int64_t* target, float* image_out, int6
                         (hipStream_t)stream);
 }
 
+int fu_assemble_tiles(const float* const* srcs, const int32_t* src_channels, int n_src, int B, int H, int W,
+                      const int32_t* valid_h, const int32_t* valid_w, int norm_mode, const float* global_mean,
+                      const float* global_std, float pad_value, float* out, float* mean_out, float* std_out,
+                      fu_stream stream) {
+  FU_REQUIRE(srcs && src_channels && out && B >= 1 && H >= 1 && W >= 1, "fu_assemble_tiles: bad argument");
+  return launch_assemble_tiles(srcs, src_channels, n_src, B, H, W, valid_h, valid_w, norm_mode, global_mean, global_std,
+                               pad_value, out, mean_out, std_out, (hipStream_t)stream);
+}
+
 // ---- single operators --------------------------------------------------------------------------------
 int fu_elem_size(int precision) { return precision == FU_F32 ? 4 : 2; }   /* FU_BF16 and FU_F16: 2 */
 

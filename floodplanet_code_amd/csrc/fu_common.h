@@ -361,6 +361,9 @@ int launch_stitch_add(const float* logits_nhwc, int ncls, int cropW, float* canv
                       int w0, int dh, int dw, hipStream_t s);
 int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t npix, int64_t* argmax_out,
                            hipStream_t s);
+int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int n_src, int B, int H, int W, const int* vh,
+                          const int* vw, int norm_mode, const float* gmean, const float* gstd, float pad_value, float* out,
+                          float* mean_out, float* std_out, hipStream_t s);
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
 int launch_scale_by_device_scalar(float* x, int64_t n, const float* scale_dev, hipStream_t s);

@@ -1681,6 +1681,106 @@ int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile assembly: per-tile normalisation (base_dataset.py:77-113), edge-crop buffer
+// (base_dataset.py:271-325) and multi-sensor channel concatenation (ef_model.py:28-44 / stacked sensors) of a whole batch
+// that is already in HBM, instead of per item in DataLoader workers.
+// ------------------------------------------------------------------------------------------------
+struct AsmSrcs { const float* p[8]; int c[8]; int coff[9]; int n; };
+
+// one block per (sample, channel): mean and POPULATION std (numpy .mean / .std, ddof = 0) over the valid crop, two passes
+// (the plane stays in L2), fp64 accumulation, fixed-order block reduction
+__global__ __launch_bounds__(256) void k_tile_stats(AsmSrcs S, int Ctot, int H, int W, const int* __restrict__ vh,
+                                                    const int* __restrict__ vw, float* __restrict__ mean_o,
+                                                    float* __restrict__ std_o) {
+  __shared__ double sm[256];
+  const int b = blockIdx.x / Ctot, c = blockIdx.x - b * Ctot;
+  int si = 0;
+  for (int k = 1; k < S.n; ++k) si = c >= S.coff[k] ? k : si;
+  const float* plane = S.p[si] + ((int64_t)b * S.c[si] + (c - S.coff[si])) * H * W;
+  const int h = vh ? vh[b] : H, w = vw ? vw[b] : W;
+  const int n = h * w;
+  auto block_sum = [&](double v) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+  };
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)plane[(i / w) * W + (i % w)];
+  const double mean = n > 0 ? block_sum(a) / n : 0.0;
+  double q = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double dlt = (double)plane[(i / w) * W + (i % w)] - mean; q += dlt * dlt; }
+  const double var = n > 0 ? block_sum(q) / n : 1.0;
+  if (threadIdx.x == 0) { mean_o[blockIdx.x] = (float)mean; std_o[blockIdx.x] = (float)sqrt(var); }
+}
+
+// out[b][c][y][x] = inside the valid crop ? (src - mean[b][c]) / std[b][c] : pad_value
+__global__ void k_assemble_tiles(AsmSrcs S, int Ctot, int H, int W, const int* __restrict__ vh, const int* __restrict__ vw,
+                                 const float* __restrict__ mean, const float* __restrict__ stdv, int per_sample,
+                                 float pad_value, float* __restrict__ out, int64_t total) {
+#pragma clang fp contract(off)      // image -= mean; image /= std: two roundings, as numpy does them
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    int64_t r = idx / W;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % Ctot);
+    const int b = (int)(r / Ctot);
+    int si = 0;
+    for (int k = 1; k < S.n; ++k) si = c >= S.coff[k] ? k : si;
+    const bool inside = y < (vh ? vh[b] : H) && x < (vw ? vw[b] : W);
+    float v = pad_value;
+    if (inside) {
+      v = S.p[si][(((int64_t)b * S.c[si] + (c - S.coff[si])) * H + y) * W + x];
+      if (mean) {
+        const int mi = per_sample ? b * Ctot + c : c;
+        const float d = v - mean[mi];
+        v = d / stdv[mi];
+      }
+    }
+    out[idx] = v;
+  }
+}
+
+int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int n_src, int B, int H, int W, const int* vh,
+                          const int* vw, int norm_mode, const float* gmean, const float* gstd, float pad_value, float* out,
+                          float* mean_out, float* std_out, hipStream_t s) {
+  FU_REQUIRE(n_src >= 1 && n_src <= 8, "assemble: 1..8 sources (got %d)", n_src);
+  AsmSrcs S;
+  S.n = n_src;
+  int off = 0;
+  for (int k = 0; k < n_src; ++k) {
+    FU_REQUIRE(srcs[k] && src_channels[k] >= 1, "assemble: bad source %d", k);
+    S.p[k] = srcs[k]; S.c[k] = src_channels[k]; S.coff[k] = off; off += src_channels[k];
+  }
+  S.coff[n_src] = off;
+  const int Ctot = off;
+  const float *mean = nullptr, *stdv = nullptr;
+  int per_sample = 0;
+  if (norm_mode == 1) {        // 'local'
+    FU_REQUIRE(mean_out && std_out, "assemble: norm_mode 'local' needs mean_out / std_out [B, sum C]");
+    hipLaunchKernelGGL(k_tile_stats, dim3(B * Ctot), dim3(256), 0, s, S, Ctot, H, W, vh, vw, mean_out, std_out);
+    FU_LAUNCH_CHECK();
+    mean = mean_out; stdv = std_out; per_sample = 1;
+  } else if (norm_mode == 2) { // 'global'
+    FU_REQUIRE(gmean && gstd, "assemble: norm_mode 'global' needs the per-channel parameters");
+    mean = gmean; stdv = gstd;
+  } else {
+    FU_REQUIRE(norm_mode == 0, "assemble: norm_mode must be 0 (None), 1 ('local') or 2 ('global')");
+  }
+  const int64_t total = (int64_t)B * Ctot * H * W;
+  hipLaunchKernelGGL(k_assemble_tiles, dim3(grid_for(total, 256)), dim3(256), 0, s, S, Ctot, H, W, vh, vw, mean, stdv,
+                     per_sample, pad_value, out, total);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Inference stitching (utils/utils_image.py:410-494, predict.py:329-347): softmax of a crop's logits is added into an
 // overlap-averaging canvas, canvas[h0:hE, w0:wE, :] += p[:dh, :dw, :], weight += 1; finalisation divides by
 // (weight + 1e-5) and emits the argmax map.

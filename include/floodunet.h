@@ -197,6 +197,18 @@ enum { FU_AUG_HFLIP = 1, FU_AUG_VFLIP = 2, FU_AUG_ROTATE = 4 };
 int fu_augment(const float* image, const int64_t* target, float* image_out, int64_t* target_out, const int32_t* flags,
                const float* angles_deg, int B, int C, int H, int W, int64_t target_fill, fu_stream stream);
 
+/* Tile assembly of a batch that is already in HBM (datasets/base_dataset.py:77-113 `normalize`, :271-325
+ * `_add_buffer_to_image`; ef_model.py:28-44 / stacked sensors: channel concatenation).  srcs: HOST array of n_src (<= 8)
+ * device pointers, source k fp32 NCHW [B, src_channels[k], H, W]; the valid crop of sample b is the top-left
+ * valid_h[b] x valid_w[b] corner (device int32 [B]; NULL = the whole tile).  out: fp32 NCHW [B, sum C, H, W] =
+ * (x - mean) / std inside the crop, pad_value outside (the reference pads the image with 0 AFTER normalising).
+ * norm_mode 0 = None (mean 0, std 1), 1 = 'local' (per sample and channel mean / population std over the crop, numpy
+ * semantics; written to mean_out / std_out fp32 [B, sum C]), 2 = 'global' (global_mean / global_std fp32 [sum C]). */
+int fu_assemble_tiles(const float* const* srcs, const int32_t* src_channels, int n_src, int B, int H, int W,
+                      const int32_t* valid_h, const int32_t* valid_w, int norm_mode, const float* global_mean,
+                      const float* global_std, float pad_value, float* out, float* mean_out, float* std_out,
+                      fu_stream stream);
+
 /* ---- inference stitching (ImageStitcher_v2, utils/utils_image.py:410-494) ------------- */
 /* canvas[h0:hE, w0:wE, :] += softmax(logits of sample `sample` of the last fu_forward)[:hE-h0, :wE-w0, :];
  * weight[h0:hE, w0:wE] += 1.  canvas: fp32 [canvas_h, canvas_w, n_classes], weight: fp32 [canvas_h, canvas_w]. */

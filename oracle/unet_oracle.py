@@ -331,6 +331,62 @@ def metrics_from_counts(m: np.ndarray, ignore_index: Optional[int] = None) -> Di
 
 
 # --------------------------------------------------------------------------- #
+# tile assembly: normalise, edge-crop buffer, channel concat (base_dataset.py:77-113, :271-325; ef_model.py:28-44)
+# --------------------------------------------------------------------------- #
+def assemble_case_sources(case):
+    """The raw tiles of a case of oracle/make_assemble_golden.py from the closed-form generator (seeds only)."""
+    out = []
+    for k, (name, ch, scale, shift) in enumerate(case["sources"]):
+        n = case["B"] * ch * case["H"] * case["W"]
+        x = hash_uniform(n, 1000 + k, sum(map(ord, case["name"]))).astype(np.float32)
+        x = x.reshape(case["B"], ch, case["H"], case["W"])
+        out.append((x * np.float32(scale) + np.float32(shift)).astype(np.float32))
+    return out
+
+
+def assemble_global_params(case):
+    return {name: {"mean": (np.arange(ch, dtype=np.float32) * np.float32(0.1 * scale) + np.float32(shift)),
+                   "std": (np.float32(scale) * (np.float32(0.5) + np.arange(ch, dtype=np.float32) * np.float32(0.05)))}
+            for (name, ch, scale, shift) in case["sources"]}
+
+
+def assemble_tiles(sources, valid, norm_mode, global_params=None, names=None, pad_value=0.0):
+    """sources: list of float32 [B, C_k, H, W]; valid: [(h_b, w_b)] -> (image [B, sum C, H, W], mean, std [B, sum C]).
+    Per sample and source: crop -> `normalize` (None: mean 0 / std 1; 'local': per-channel mean and population std of the
+    crop, `flat.mean(axis=1)` / `flat.std(axis=1)`; 'global': the dataset's parameters; then `image -= mean; image /= std`,
+    base_dataset.py:95-111) -> `_add_buffer_to_image` (constant 0 canvas of the nominal size, crop in the top-left corner,
+    :306-320) -> concatenation along the channel axis.  PINNED: tests/golden/assemble_golden.npz was produced by the
+    reference's own two methods (oracle/make_assemble_golden.py)."""
+    B, _, H, W = sources[0].shape
+    ctot = sum(s.shape[1] for s in sources)
+    image = np.full((B, ctot, H, W), pad_value, dtype=np.float32)
+    mean = np.zeros((B, ctot), dtype=np.float32)
+    std = np.ones((B, ctot), dtype=np.float32)
+    for b in range(B):
+        vh, vw = valid[b]
+        c0 = 0
+        for k, x in enumerate(sources):
+            ch = x.shape[1]
+            crop = x[b, :, :vh, :vw].copy()
+            if norm_mode == "local":
+                flat = crop.reshape(ch, vh * vw)
+                m, s = flat.mean(axis=1), flat.std(axis=1)
+            elif norm_mode == "global":
+                m, s = global_params[names[k]]["mean"], global_params[names[k]]["std"]
+            elif norm_mode is None:
+                m, s = np.zeros(ch, dtype=crop.dtype), np.ones(ch, dtype=crop.dtype)
+            else:
+                raise NotImplementedError(f'Normalization mode "{norm_mode}" not implemented.')
+            crop -= m[:, None, None]
+            crop /= s[:, None, None]
+            image[b, c0:c0 + ch, :vh, :vw] = crop
+            mean[b, c0:c0 + ch] = m
+            std[b, c0:c0 + ch] = s
+            c0 += ch
+    return image, mean, std
+
+
+# --------------------------------------------------------------------------- #
 # overlap-average stitching of tile predictions (utils/utils_image.py:363-494 as predict.py:296-334 drives it)
 # --------------------------------------------------------------------------- #
 def stitch_reference(logits: np.ndarray, boxes, H: int, W: int):

@@ -379,3 +379,37 @@ def test_gpu_augmentation_matches_oracle_and_flip_identities():
     sq = torch.rand(1, 2, 32, 32, generator=g)
     o2, _ = augment.apply(sq.to(DEV), None, [4], [90.0])
     assert torch.equal(o2.cpu()[0], torch.rot90(sq[0], 1, dims=(-2, -1)))
+
+
+def test_gpu_tile_assembly_matches_reference_fixture():
+    """fu_assemble_tiles (normalise + edge-crop buffer + multi-sensor concat on the GPU) against the fixture produced by the
+    reference's own `normalize` / `_add_buffer_to_image` (oracle/make_assemble_golden.py).  None and 'global': the same two
+    float32 operations as numpy -> exact; 'local': the statistics are accumulated in fp64 here and pairwise in float32 by
+    numpy -> 1e-6 relative on mean / std, 3e-6 of the value range on the normalised image."""
+    import json, os
+    from conftest import GOLDEN
+    from floodplanet_code_amd.datasets.assemble import assemble_tiles
+    from oracle import unet_oracle as O
+    z = np.load(os.path.join(GOLDEN, "assemble_golden.npz"))
+    for case in json.loads(bytes(z["meta"]).decode()):
+        srcs = [torch.from_numpy(x).to(DEV) for x in O.assemble_case_sources(case)]
+        vh = torch.tensor([v[0] for v in case["valid"]], dtype=torch.int32)
+        vw = torch.tensor([v[1] for v in case["valid"]], dtype=torch.int32)
+        gp = None
+        if case["norm_mode"] == "global":
+            g = O.assemble_global_params(case)
+            gp = (torch.from_numpy(np.concatenate([g[s[0]]["mean"] for s in case["sources"]])),
+                  torch.from_numpy(np.concatenate([g[s[0]]["std"] for s in case["sources"]])))
+        img, mean, std = assemble_tiles(srcs, case["norm_mode"], (vh, vw), gp)
+        torch.cuda.synchronize()
+        n = case["name"]
+        ref = z[n + "_image"]
+        B, ctot = ref.shape[:2]
+        np.testing.assert_allclose(mean.cpu().numpy().reshape(B, ctot), z[n + "_mean"], rtol=1e-6, atol=0, err_msg=n)
+        np.testing.assert_allclose(std.cpu().numpy().reshape(B, ctot), z[n + "_std"], rtol=1e-6, atol=0, err_msg=n)
+        if case["norm_mode"] == "local":
+            np.testing.assert_allclose(img.cpu().numpy(), ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()), err_msg=n)
+        else:
+            np.testing.assert_array_equal(img.cpu().numpy(), ref, err_msg=n)
+    with pytest.raises(NotImplementedError):
+        assemble_tiles(srcs, "bogus")

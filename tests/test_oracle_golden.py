@@ -121,3 +121,19 @@ def test_oracle_stitching_matches_the_reference_class(name):
     x[0, :, :hE - h0, :wE - w0] = big[:, h0:hE, w0:wE]
     lg = O.eval_forward(st, {"image": x})
     np.testing.assert_allclose(lg[0].numpy(), z["logits"][-1], rtol=0, atol=2e-5)
+
+
+def test_oracle_tile_assembly_matches_the_reference_methods():
+    """O.assemble_tiles against outputs of the reference's own `BaseDataset.normalize` / `_add_buffer_to_image`
+    (AST-extracted and run in the build container by oracle/make_assemble_golden.py): None / local / global normalisation,
+    several sensors, edge crops smaller than the nominal tile."""
+    z = np.load(os.path.join(GOLDEN, "assemble_golden.npz"))
+    for case in json.loads(bytes(z["meta"]).decode()):
+        srcs = O.assemble_case_sources(case)
+        names = [s[0] for s in case["sources"]]
+        image, mean, std = O.assemble_tiles(srcs, [tuple(v) for v in case["valid"]], case["norm_mode"],
+                                            O.assemble_global_params(case), names)
+        n = case["name"]
+        np.testing.assert_allclose(mean, z[n + "_mean"], rtol=1e-6, atol=0, err_msg=n)
+        np.testing.assert_allclose(std, z[n + "_std"], rtol=1e-6, atol=0, err_msg=n)
+        np.testing.assert_allclose(image, z[n + "_image"], rtol=0, atol=2e-6 * max(1.0, np.abs(z[n + "_image"]).max()), err_msg=n)
