@@ -1258,7 +1258,9 @@ int fu_profile_read(fu_ctx* c, int kernel_class, int64_t* launches, double* tota
   if (total_flops) *total_flops = fl;
   if (kernel_name)
     *kernel_name = kernel_class == FU_K_CONV3X3
-                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : (c->prec == PREC_BF16 ? "k_conv3x3_bf16_fast" : "k_conv3x3_f16_fast"))
+                       // 16-bit: the class = every forward / dgrad launch, i.e. k_conv3x3_bf16_rs<8|4> and the
+                       // k_conv3x3_bf16_fast<...> instantiations (the common prefix matches them all in a kernel trace)
+                       ? (c->prec == PREC_F32 ? "k_conv3x3_f32" : (c->prec == PREC_BF16 ? "k_conv3x3_bf16" : "k_conv3x3_f16"))
                        : (c->prec == PREC_F32 ? "k_wgrad_f32" : (c->prec == PREC_BF16 ? "k_wgrad_bf16" : "k_wgrad_f16"));
   return FU_OK;
 }

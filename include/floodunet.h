@@ -225,7 +225,7 @@ int fu_flops_per_tile(const fu_ctx* ctx, double* fwd, double* train);
 
 /* ---- profiling: HIP events around the convolution kernels (bench.py's roofline object) -------- */
 enum fu_kernel_class {
-  FU_K_CONV3X3 = 0, /* implicit-GEMM 3x3 conv kernel: forward and dgrad launches */
+  FU_K_CONV3X3 = 0, /* implicit-GEMM 3x3 conv kernels: forward and dgrad launches (16-bit: k_conv3x3_*_rs + k_conv3x3_*_fast) */
   FU_K_WGRAD = 1,   /* weight-gradient kernel (without its slab reduce) */
   FU_K_NUM = 2
 };

@@ -1,9 +1,14 @@
-"""Per-launch HBM bytes and SQ ratios of the MFMA kernels from the separate rocprofv3 --pmc passes of tools/prof_all.sh.
-usage: python tools/pmc_summary.py gpurun_out > profiles/r1_pmc_bf16.json
-FETCH_SIZE is doubled (gfx950: wide coalesced reads are tallied at 1/2, MI355X_MICROARCH.md, HBM section); units KB."""
-import csv, glob, json, sys, statistics as st
+"""Per-launch HBM bytes and SQ ratios of the MFMA kernel classes from the separate rocprofv3 --pmc passes of tools/prof_all.sh.
+usage: python tools/pmc_summary.py gpurun_out [bf16|f16] > profiles/r2_pmc_bf16.json
+FETCH_SIZE is doubled (gfx950: wide coalesced reads are tallied at 1/2, MI355X_MICROARCH.md, HBM section); units KB.
+The output records `csrc_sha` = the hash of floodplanet_code_amd/csrc/*.{hip,h} the profiled library was built from (the box
+runs a snapshot of this tree): bench.py reports `roofline.traffic` from this file only while its own sources hash the same."""
+import csv, glob, json, os, sys, statistics as st
 root = sys.argv[1]
-KERNELS = {"k_conv3x3_bf16_fast": "k_conv3x3_bf16_fast", "k_wgrad_bf16": "k_wgrad_bf16"}
+dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# class key (what fu_profile_read / bench.py call the class) -> substring of the kernel names it covers
+KERNELS = {f"k_conv3x3_{dt}": f"k_conv3x3_{dt}", f"k_wgrad_{dt}": f"k_wgrad_{dt}"}
 
 def rows(sub):
     out = []
@@ -43,5 +48,7 @@ for k in KERNELS:
         d["sq_pmc"] = {"mfma_busy_over_4x_cu_busy_median": round(st.median(mf), 3), "lds_active_over_cu_busy_median": round(st.median(la), 3),
                        "lds_bank_conflict_over_lds_active_median": round(st.median(lc), 3)}
     out[k] = d
+import bench  # noqa: E402  (csrc_sha only; nothing touches the GPU)
+out["csrc_sha"] = bench.csrc_sha()
 out["command"] = "tools/prof_all.sh: rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ set> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (bf16, B=16, 8ch, 256x256); summarised by tools/pmc_summary.py"
 print(json.dumps(out, indent=1))
