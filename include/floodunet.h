@@ -237,6 +237,8 @@ int fu_profile_enable(fu_ctx* ctx, int enable);
 int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
                     const char** kernel_name);
 
+/* ---- TEST HOOKS: process-wide switches that let the parity tests run every shape on every kernel variant.  NOT part of
+ * the stable ABI (no version bump when they change); never needed by a caller. -------------------------------------- */
 /* Testing hook: on != 0 makes every bf16 3x3 convolution (forward / dgrad) run on the general kernel even when the
  * shape is eligible for the aligned-shape fast kernel, so that the parity tests can cover both.  Process-wide. */
 void fu_test_force_general_conv(int on);
@@ -244,7 +246,8 @@ void fu_test_force_general_conv(int on);
  * the ping-pong kernel k_wgrad_bf16_pp (same accumulation order: the results are bit-identical).  Process-wide. */
 void fu_test_force_lockstep_wgrad(int on);
 /* Testing hook: workgroup tile of the aligned-shape bf16 conv kernel at 64 output channels: 0 = heuristic (default),
- * 1 = never the tall 16x32-pixel tile, 2 = the tall tile wherever 64-channel tiles run.  Process-wide. */
+ * 1 = never the tall 16x32-pixel tile (nor the row-stationary kernel), 2 = the tall tile wherever 64-channel tiles run,
+ * 3 = the row-stationary kernel (fu_conv_rs.hip) wherever the shape is eligible.  Process-wide. */
 void fu_test_conv_tile_mode(int mode);
 /* Testing hook: on != 0 runs the late-fusion 1x1 convs (weights embedded as the centre tap of a 3x3) through all nine taps
  * instead of the 1-tap instantiation of the fast kernel; the other eight taps multiply exact zeros, so the results are
