@@ -100,7 +100,9 @@ def launch_ranks(n, argv):
         time.sleep(0.1)
     rcs = [p.wait() for p in procs]
     reader.join(timeout=10)
-    sys.stdout.write(b"".join(chunks).decode("utf-8", "replace"))
+    for line in b"".join(chunks).decode("utf-8", "replace").splitlines():
+        # stdout carries exactly the JSON line(s); anything else a rank printed there (gloo's connection banner) goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad or failed:
