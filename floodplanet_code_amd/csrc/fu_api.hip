@@ -193,6 +193,7 @@ struct Conv {
   float *mean = nullptr, *invstd = nullptr, *a = nullptr, *b = nullptr, *coef = nullptr;
   void* y = nullptr;
   void* gy = nullptr;
+  const void* pool_g = nullptr;   // backward: dL/d(maxpool(this output)), to be folded into this conv's BN backward
 };
 
 enum BlockKind { BK_INC = 0, BK_DOWN = 1, BK_UP = 2 };
@@ -800,7 +801,8 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   float* dbp = (side && par) ? c->db_part2 : c->db_part;
   if (side && c->wg_pending[par]) FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_wg[par], 0));   // buffer free again
   FU_TRY(launch_bn_bwd(c->prec, v.gy, v.y, v.cout, npix, v.a, v.b, v.mean, v.invstd, P(c, v.p_g), G(c, v.p_g),
-                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s));
+                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s, v.pool_g, B, H, W));
+  v.pool_g = nullptr;
   // weight (and bias) gradient
   const ConvIn in = conv_input(c, i, j);
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
@@ -828,9 +830,14 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.g_pooled, v.cin_real, nullptr, 0, nullptr, nullptr, B, H, W,
                           s));
+    // the pool's backward (route g_pooled to the first argmax of every window, add to the skip gradient) is folded into
+    // the BN backward of the pooled tensor: the next backward block on this stream (k_bn_bwd_pool)
     Conv& pv = c->blk[i - 1].c[1];
-    FU_TRY(launch_maxpool2_bwd(c->prec, K.g_pooled, pv.y, pv.a, pv.b, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level],
-                               pv.cout, s));
+    if (getenv("FU_POOL_BWD_SEPARATE"))
+      FU_TRY(launch_maxpool2_bwd(c->prec, K.g_pooled, pv.y, pv.a, pv.b, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level],
+                                 pv.cout, s));
+    else
+      pv.pool_g = K.g_pooled;
   } else if (K.kind == BK_UP) {
     const Feat sk = level_feat(c, K.skip);
     const Feat pv = low_feat(c, i);

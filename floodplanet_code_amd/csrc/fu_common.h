@@ -294,10 +294,12 @@ int launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const fl
                           const float* running_var, float eps, float* a, float* b, hipStream_t s);
 // backward: g (in place -> dy).  Two launches + finalize inside.  partials scratch: >= bn_bwd_partial_elems.
 int64_t bn_bwd_partial_elems(int C, int64_t npix);
+// g_pool != null: y's 2x2 max-pool ran in forward and g_pool [B, H/2, W/2, C] is dL/d(pooled): the pool's backward is folded
+// into the two passes (g is then the skip gradient only)
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s);
+                  hipStream_t s, const void* g_pool = nullptr, int B = 0, int H = 0, int W = 0);
 
 int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                     hipStream_t s);

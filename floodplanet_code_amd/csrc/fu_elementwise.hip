@@ -461,6 +461,112 @@ __global__ void k_bn_bwd_apply(T* __restrict__ g, const T* __restrict__ y, int C
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward with the max-pool backward folded in (round 2).  For the four encoder outputs that feed a pool,
+// dL/d relu(bn(y)) = g (the skip gradient written by the decoder's dgrad) + the pooled gradient routed to the first argmax
+// of every 2x2 window.  k_maxpool2_bwd used to add that into g in a read-modify-write pass of its own (a y-sized read, a
+// g-sized read and write); here one thread owns a whole 2x2 window x 4 channels, recomputes the window's activations (it
+// needs them for the ReLU mask anyway), routes the pooled gradient in registers and does the BN-backward reduction /
+// apply on the four pixels.  Same tie rule (first maximum in row-major order, as ATen), same fixed-order block partials.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool APPLY>
+__global__ void k_bn_bwd_pool(T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ gpool, int C, int B,
+                              int H, int W, const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                              const float* __restrict__ coef, float* __restrict__ partials) {
+  extern __shared__ float sm[];  // APPLY: [rows][C] (sum dy);  reduce: [rows][C][2]
+  const int CV = C >> 2;
+  const int rows = BNB_THREADS / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  const int Ho = H >> 1, Wo = W >> 1, Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;     // pool outputs; windows incl. odd edges
+  const int64_t nwin = (int64_t)B * Hw * Ww;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (row < rows) {
+    float av[4], bv[4], mv[4], iv[4], c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    ElemIO<float>::load4(a + cv * 4, av);
+    ElemIO<float>::load4(b + cv * 4, bv);
+    ElemIO<float>::load4(mean + cv * 4, mv);
+    ElemIO<float>::load4(invstd + cv * 4, iv);
+    if (APPLY) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c1[j] = coef[(cv * 4 + j) * 2 + 0]; c2[j] = coef[(cv * 4 + j) * 2 + 1]; }
+    }
+    for (int64_t wi = (int64_t)blockIdx.x * rows + row; wi < nwin; wi += (int64_t)gridDim.x * rows) {
+      const int wx = (int)(wi % Ww);
+      const int64_t r = wi / Ww;
+      const int wy = (int)(r % Hw);
+      const int64_t bb = r / Hw;
+      const bool pooled = wy < Ho && wx < Wo;                     // complete window: has a pool output
+      float yv[4][4], gv[4][4], z[4][4], gp[4] = {0, 0, 0, 0};
+      bool ok[4];
+      int64_t off[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int py = 2 * wy + (q >> 1), px = 2 * wx + (q & 1);
+        ok[q] = py < H && px < W;
+        off[q] = (((bb * H + (ok[q] ? py : 0)) * W + (ok[q] ? px : 0)) * (int64_t)C) + cv * 4;
+        ElemIO<T>::load4(y + off[q], yv[q]);
+        ElemIO<T>::load4(g + off[q], gv[q]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[q][j] = bn_act_pre(av[j], yv[q][j], bv[j]);
+      }
+      if (pooled) ElemIO<T>::load4(gpool + (((bb * Ho + wy) * Wo + wx) * (int64_t)C) + cv * 4, gp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int am = 0;
+        float m = fmaxf(z[0][j], 0.f);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+          const float zq = fmaxf(z[q][j], 0.f);
+          if (zq > m) { m = zq; am = q; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q][j] += (am == q) ? gp[j] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gm = (z[q][j] > 0.f && ok[q]) ? gv[q][j] : 0.f;
+          const float xh = (yv[q][j] - mv[j]) * iv[j];
+          if (APPLY) {
+            o[j] = av[j] * (gm - c1[j] - xh * c2[j]);
+            s1[j] += ok[q] ? o[j] : 0.f;
+          } else {
+            s1[j] += gm;
+            s2[j] += gm * xh;
+          }
+        }
+        if (APPLY && ok[q]) ElemIO<T>::store4(g + off[q], o);
+      }
+    }
+    if (APPLY) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sm[row * C + cv * 4 + j] = s1[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sm[((row * C) + cv * 4 + j) * 2 + 0] = s1[j];
+        sm[((row * C) + cv * 4 + j) * 2 + 1] = s2[j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += BNB_THREADS) {
+    if (APPLY) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += sm[r * C + c];
+      partials[(int64_t)blockIdx.x * C + c] = t;
+    } else {
+      float t1 = 0.f, t2 = 0.f;
+      for (int r = 0; r < rows; ++r) { t1 += sm[(r * C + c) * 2 + 0]; t2 += sm[(r * C + c) * 2 + 1]; }
+      partials[((int64_t)blockIdx.x * C + c) * 2 + 0] = t1;
+      partials[((int64_t)blockIdx.x * C + c) * 2 + 1] = t2;
+    }
+  }
+}
+
 static int bn_bwd_blocks(int C, int64_t npix) {
   const int rows = BNB_THREADS / (C >> 2);
   int64_t nb = ceil_div64(npix, (int64_t)rows * 8);  // ~8 pixels per thread
@@ -470,16 +576,34 @@ static int bn_bwd_blocks(int C, int64_t npix) {
 }
 int64_t bn_bwd_partial_elems(int C, int64_t npix) { return (int64_t)bn_bwd_blocks(C, npix) * C * 2; }
 
+template <typename T>
+static void launch_bn_bwd_pool_t(bool apply, int nb, size_t sh, hipStream_t s, void* g, const void* y, const void* gpool,
+                                 int C, int B, int H, int W, const float* a, const float* b, const float* mean,
+                                 const float* invstd, const float* coef, float* partials) {
+  if (apply)
+    hipLaunchKernelGGL((k_bn_bwd_pool<T, true>), dim3(nb), dim3(BNB_THREADS), sh, s, (T*)g, (const T*)y, (const T*)gpool, C,
+                       B, H, W, a, b, mean, invstd, coef, partials);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_pool<T, false>), dim3(nb), dim3(BNB_THREADS), sh, s, (T*)g, (const T*)y, (const T*)gpool,
+                       C, B, H, W, a, b, mean, invstd, coef, partials);
+}
+
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s) {
+                  hipStream_t s, const void* g_pool, int B, int H, int W) {
   (void)gamma;
   FU_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: channels must be a multiple of 4 and <= 1024 (got %d)", C);
   const int nb = bn_bwd_blocks(C, npix);
   const int rows = BNB_THREADS / (C >> 2);
   const size_t sh1 = (size_t)rows * C * 2 * sizeof(float);
-  if (p == PREC_F32)
+  const bool pool = g_pool != nullptr;     // the max-pool backward of this tensor is folded into the two passes
+  if (pool) {
+    FU_REQUIRE((int64_t)B * H * W == npix && BNB_THREADS % (C >> 2) == 0, "bn_bwd (pooled): bad geometry");
+    if (p == PREC_F32) launch_bn_bwd_pool_t<float>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
+    else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
+    else launch_bn_bwd_pool_t<f16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
+  } else if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const float*)g, (const float*)y,
                        C, npix, a, b, mean, invstd, partials);
   else if (p == PREC_BF16)
@@ -502,7 +626,11 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     FU_LAUNCH_CHECK();
   }
   const size_t sh2 = (size_t)rows * C * sizeof(float);
-  if (p == PREC_F32)
+  if (pool) {
+    if (p == PREC_F32) launch_bn_bwd_pool_t<float>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
+    else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
+    else launch_bn_bwd_pool_t<f16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
+  } else if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(nb), dim3(BNB_THREADS), sh2, s, (float*)g, (const float*)y, C, npix,
                        a, b, mean, invstd, coef, db_partials);
   else if (p == PREC_BF16)
