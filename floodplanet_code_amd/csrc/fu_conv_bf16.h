@@ -98,7 +98,18 @@ __device__ __forceinline__ unsigned pack_e2(f32x2 v) {
 }
 
 // relu(a * x + b) on the two 16-bit channels of one dword; one rounding to the element type
+#ifndef FU_PACKED_BN
+#define FU_PACKED_BN 0
+#endif
 __device__ __forceinline__ unsigned bn_relu_pair(unsigned v, f32x2 a, f32x2 b) {
+#if !FU_PACKED_BN
+  // plain v_fma_f32 / v_max_f32 per channel.  The packed-f32 form below is three instructions shorter per pair and was
+  // round 1's choice, but packed f32 VALU is slow beside a co-resident wave's MFMAs (MI355X_MICROARCH.md, "price of one
+  // filler": +22 cycles per v_pk_fma_f32): s_memtime stamps of the row-stationary kernel's staging phase, 10 units per
+  // thread and chunk: 6000 cycles packed, 3300 plain (tools/stamp_rs.py)
+  const float lo = fmaxf(fmaf(a.x, e2f_lo(v), b.x), 0.f), hi = fmaxf(fmaf(a.y, e2f_hi(v), b.y), 0.f);
+  return pack_e2(f32x2{lo, hi});
+#endif
   f32x2 x = e2f_pair(v);
   x = __builtin_elementwise_fma(a, x, b);                                    // v_pk_fma_f32 (= bn_act_fused per lane)
   const s16x2 h = __builtin_bit_cast(s16x2, pack_e2(x));
@@ -116,6 +127,7 @@ struct BConvP {
   bf16_t* dst0; bf16_t* dst1; float* stats;
   int C0, C1, Cin, N, D0, D1, B, H, W, tilesX, tilesY, nPix, nCo;
   unsigned rcp_nPix, rcp_tilesX, rcp_tilesY;   // fast path: floor(2^32 / d) + 1 (0 for d == 1)
+  unsigned rcp_nCo;                            // row-stationary kernel: channel tile fastest in the workgroup order
   unsigned long long* dbg;   // optional s_memtime stamps per workgroup (tools/stamp_test.py; FU_CONV_STAMPS builds)
   int center_only;           // 1: every tap but the centre one of wpk is zero (embedded 1x1): the fast kernel skips them
 };

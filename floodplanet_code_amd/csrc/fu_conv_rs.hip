@@ -62,9 +62,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave = 8 output rows of the tile
   const int lx = lane & 15, lg = lane >> 4;                        // pixel column / channel row m, and k-group (8 channels)
 
+#ifndef FU_RS_PIXEL_MAJOR
+#define FU_RS_PIXEL_MAJOR 1
+#endif
+  // Workgroup order inside an XCD's contiguous share of the grid (xcd_remap): the CHANNEL tile runs fastest, so the nCo
+  // workgroups that read the same activation tile sit on one XCD next to each other in time and the tile is fetched into
+  // that L2 once.  (Channel-tile-major order, as in the round-1 kernels, makes every XCD stream the whole input: with
+  // stamps the "A convert" phase measured 6000-7000 cycles per chunk waiting for its loads -- 152 KB per CU every 6 us =
+  // 6.3 TB/s chip-wide through the fabric, the kernel was memory-system bound on L2 misses, not on its instructions.)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
+#if FU_RS_PIXEL_MAJOR
+  const int pixT = fast_div(logical, P.nCo, P.rcp_nCo);
+  const int coT = logical - pixT * P.nCo;
+#else
   const int coT = fast_div(logical, P.nPix, P.rcp_nPix);
   const int pixT = logical - coT * P.nPix;
+#endif
   const int t2 = fast_div(pixT, P.tilesX, P.rcp_tilesX);
   const int tx = pixT - t2 * P.tilesX;
   const int bb = fast_div(t2, P.tilesY, P.rcp_tilesY);
@@ -178,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
     pfb[dx] = sA + (wm * Cfg::ROWS * HWd + lx + dx) * ROWB + ((16 * lg) ^ (((lx + dx) & 4) << 3));
 
   const int nChunks = P.Cin / KC;
+#ifdef FU_CONV_STAMPS     // diagnostic builds only (tools/stamp_rs.py): s_memtime sums per phase, wave 0
+  unsigned long long T0 = __builtin_amdgcn_s_memtime(), T1 = 0, Sbar = 0, Sstore = 0, Swait = 0, Smfma = 0, Sload = 0, Sdma = 0;
+#endif
   load_begin(0);
   static_for<0, A_ITERS>([&](auto Sc) { load_slot(Sc); });
   dma_weights(0);                                   // LDS is free at kernel start
@@ -223,29 +239,77 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
         });
         if constexpr (LOADS) {
           // 6 * IN_ROWS steps (60 / 36); one load every LS-th step covers the A_ITERS slots (10 / 6)
-          constexpr int step = (dx * 2 + sp) * Cfg::IN_ROWS + ri, LS = (6 * Cfg::IN_ROWS) / (A_ITERS + 1);
+#ifndef FU_RS_LOAD_STRIDE
+#define FU_RS_LOAD_STRIDE 0       // 0: spread over the whole block; n: one load every n-th step from the block's start
+#endif
+          constexpr int step = (dx * 2 + sp) * Cfg::IN_ROWS + ri,
+                        LS = FU_RS_LOAD_STRIDE > 0 ? FU_RS_LOAD_STRIDE : (6 * Cfg::IN_ROWS) / (A_ITERS + 1);
           if constexpr (step % LS == 0 && step / LS < A_ITERS) load_slot(std::integral_constant<int, step / LS>{});
         }
       });
     });
   };
   auto stage = [&](int k0, bool first) {
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                // every wave is done reading the previous chunk's fragments
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef FU_RS_STAGE_PRIO
+#define FU_RS_STAGE_PRIO 2
+#endif
+    // The co-resident workgroup's wave on this SIMD is (mostly) in its MFMA block: at equal priority its stream wins the
+    // vector-issue arbitration by age and this conversion crawls (measured: 6000-7000 cycles for ~250 instructions, more
+    // than the 5360-cycle MFMA block it should hide under).  An MFMA needs one issue slot per 16 cycles: raising the
+    // STAGING wave lets its VALU take the slots in between.
+    __builtin_amdgcn_s_setprio(FU_RS_STAGE_PRIO);
     if (!first) dma_weights(k0);    // the weights land while this wave converts its activation units
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s1a = __builtin_amdgcn_s_memtime();
+    if (!first) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the activation loads (older than the nine DMA pieces)
+    const unsigned long long s1b = __builtin_amdgcn_s_memtime();
+    Sload += s1b - s1a;
+    Sdma += s1a - s1;
+#endif
     const bool bn = has_bn && k0 < P.C0;             // uniform
     if (border) { if (bn) store_chunk(k0, std::true_type{}, std::true_type{}); else store_chunk(k0, std::true_type{}, std::false_type{}); }
     else { if (bn) store_chunk(k0, std::false_type{}, std::true_type{}); else store_chunk(k0, std::false_type{}, std::false_type{}); }
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed (nothing else orders them)
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
+#ifdef FU_CONV_STAMPS
+    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+    Sbar += s1 - s0; Sstore += s2 - s1; Swait += s3 - s2;
+#endif
   };
   for (int ch = 0; ch + 1 < nChunks; ++ch) {
     const int k0 = ch * KC;
     stage(k0, ch == 0);
     load_begin(k0 + KC);
+#ifdef FU_CONV_STAMPS
+    const unsigned long long m0 = __builtin_amdgcn_s_memtime();
+    if (ch == 0) T1 = m0;
+#endif
     mfma_block(std::true_type{});
+#ifdef FU_CONV_STAMPS
+    Smfma += __builtin_amdgcn_s_memtime() - m0;
+#endif
   }
   stage((nChunks - 1) * KC, nChunks == 1);
+#ifdef FU_CONV_STAMPS
+  const unsigned long long m1 = __builtin_amdgcn_s_memtime();
+  if (nChunks == 1) T1 = m1;
+#endif
   mfma_block(std::false_type{});
+#ifdef FU_CONV_STAMPS
+  const unsigned long long T2 = __builtin_amdgcn_s_memtime();
+  Smfma += T2 - m1;
+#endif
 
   // ---- epilogue: lane (pixel lx, group lg) holds channels n0 + 16 lg + [0, 16) of its pixel in every output row
   const bool to0 = n0 < P.D0;                                   // uniform: D0 % 64 == 0 with two destinations
@@ -305,6 +369,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
       o[1] = q;
     }
   }
+#ifdef FU_CONV_STAMPS
+  if (P.dbg && tid == 0) {
+    const unsigned long long T2c = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = P.dbg + (size_t)blockIdx.x * 10;
+    d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = Sbar; d[5] = Sstore; d[6] = Swait; d[7] = Smfma; d[8] = T2c; d[9] = Sload + (Sdma << 32);
+  }
+#endif
 }
 
 bool conv3x3_rs_eligible(const BConvP& P) {
@@ -326,7 +399,9 @@ static int launch_rs_cfg(BConvP& P, hipStream_t s) {
   P.tilesX = P.W / Cfg::TW; P.tilesY = P.H / Cfg::TH;
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = P.N / Cfg::BN;
   P.rcp_nPix = host_rcp(P.nPix); P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
-  FU_REQUIRE((int64_t)P.nPix * P.nCo * P.nPix < ((int64_t)1 << 32), "conv3x3_rs: grid too large (%d x %d)", P.nPix, P.nCo);
+  P.rcp_nCo = host_rcp(P.nCo);
+  FU_REQUIRE((int64_t)P.nPix * P.nCo * P.nPix < ((int64_t)1 << 32) && (int64_t)P.nPix * P.nCo * P.nCo < ((int64_t)1 << 32),
+             "conv3x3_rs: grid too large (%d x %d)", P.nPix, P.nCo);
   static bool attr_set = false;
   if (!attr_set) {
     FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_rs<ROWS_>),
