@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
 
   const int nChunks = P.Cin / KC;
 #ifdef FU_CONV_STAMPS     // diagnostic builds only (tools/stamp_rs.py): s_memtime sums per phase, wave 0
+  const unsigned long long R0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz: cycles / ticks = the clock the chip holds
   unsigned long long T0 = __builtin_amdgcn_s_memtime(), T1 = 0, Sbar = 0, Sstore = 0, Swait = 0, Smfma = 0, Sload = 0, Sdma = 0;
 #endif
   load_begin(0);
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
     const unsigned long long T3 = __builtin_amdgcn_s_memtime();
     unsigned long long* d = P.dbg + (size_t)blockIdx.x * 10;
     d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = Sbar; d[5] = Sstore; d[6] = Swait; d[7] = Smfma; d[8] = T2c; d[9] = Sload + (Sdma << 32);
+    P.dbg[(size_t)gridDim.x * 10 + blockIdx.x] = __builtin_amdgcn_s_memrealtime() - R0;
   }
 #endif
 }
