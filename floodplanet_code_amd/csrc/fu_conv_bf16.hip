@@ -416,6 +416,7 @@ struct BWgP {
   const bf16_t* src0; const bf16_t* src1; const float* a0; const float* b0; const bf16_t* dy;
   float* slab;
   int C0, C1, Cin, Cout, B, H, W, tilesX, tilesY, nPix, nCi, nCo, S, perSplit;
+  unsigned rcp_tilesX, rcp_tilesY;   // k_wgrad_bf16_pp<true>: floor(2^32 / d) + 1 (0 for d == 1), as in BConvP
   unsigned long long* dbg;   // FU_CONV_STAMPS builds: per-workgroup phase sums (tools/stamp_wgrad.py)
 };
 
@@ -642,15 +643,20 @@ __global__ __launch_bounds__(128 * WMI) void k_wgrad_bf16(BWgP P) {
 #ifdef FU_CONV_STAMPS
   const unsigned long long tE = __builtin_amdgcn_s_memtime();
 #endif
+  // slab[split][tap][Cin / 4][Cout][4] (see k_wgrad_transpose<true>): accumulator registers 4j .. 4j+3 of a lane are c_in
+  // 8j + 4 lh + {0..3} of its c_out -- one 16-byte store, 512 contiguous bytes per 32 lanes
   const int co = co0 + ni * 32 + l31;
   if (co < P.Cout) {
+    const int cq = P.Cin >> 2;                       // Cin % 8 == 0 (launch_conv3x3_wgrad_bf16)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int tap = TAPS == 9 ? t : 4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[t][r];
+      for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + mi * 32 + 8 * j + 4 * lh;
+        if (ci < P.Cin)
+          *reinterpret_cast<float4*>(P.slab + ((((int64_t)split * 9 + tap) * cq + (ci >> 2)) * P.Cout + co) * 4) =
+              make_float4(acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]);
       }
     }
   }
@@ -690,6 +696,18 @@ struct WPCfg {
   static_assert((NHP * XQ) % 2 == 0 && XH_UNITS % XQ == 0 && DH_UNITS % DQ == 0, "halves split on row boundaries");
 };
 
+//
+// FAST (round 2): the staging half of a stage was ~470 instructions per thread against 72 MFMAs of the other group -- the
+// stage was issue-bound on tile decode (three integer divisions), per-slot bounds tests, 64-bit address products, per-slot
+// select masks and one convert + one permute per CHANNEL.  With whole tiles (H % 8 == 0, W % 16 == 0), whole channel tiles
+// (Cin % 128 == 0, Cout % 64 == 0) and < 2^24 pixels everything per slot is a thread constant: the byte offset of the slot
+// from the tile's origin pixel (relX / relD), four bit sets naming the slots that fall off the image when the tile touches
+// the top / bottom / left / right border, and LDS addresses that differ by immediates.  Per stage the decode is scalar
+// (multiply-high by host reciprocals), a load is one add (+ the 64-bit base), interior tiles carry no masks at all, and
+// the BatchNorm + ReLU converts channel PAIRS (v_cvt_pk with both operands).  Lanes of an un-normalised second source take
+// a = 1, b = 0 and a NaN floor (v_max_f32 returns the other operand), so the stream has no divergent branch.  The
+// arithmetic per element is unchanged: results are bit-identical to FAST = false, which keeps every other shape.
+template <bool FAST>
 __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   using Cfg = WPCfg;
   constexpr int CI_T = Cfg::CI_T, CO_T = Cfg::CO_T, GT = Cfg::GT, HWd = Cfg::HWd, NHP = Cfg::NHP;
@@ -700,7 +718,14 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   float* sAB = reinterpret_cast<float*>(sBuf + 2 * Cfg::BUF_ELEMS);         // [2][CI_T]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int grp = wave >> 2, tg = tid & (GT - 1);
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & (GT - 1);
+  // staging halves: group 1 stages the TOP half of a stage (halo rows 0-4, dy rows 0-3), group 0 the bottom half.  A group
+  // stores its half of its next stage right before it multiplies that stage; the other half was stored by the other
+  // group one interval earlier, i.e. in front of a barrier this group has already passed.  With the top half coming from
+  // the OTHER group, the first fragments of the next MFMA phase (row 0) can be requested before the barrier that ends
+  // the staging, and their LDS latency (the phase measured 2650 cycles for 2304 of MFMA work with an idle partner: the
+  // pipe waits ~250 cycles for its first fragments) overlaps the barrier wait.
+  const int hg = 1 - grp;
   const int mi = wave & 3;                 // c_in block of this wave; both c_out blocks: see ni below
   // waves 0-3 and 4-7 must split the MFMA work so that each group covers all (mi, ni): wave = 4*grp + w, w = 0..3
   // -> group g owns c_out block ni = g, all four c_in blocks
@@ -753,7 +778,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   uint4 rx[X_ITERS], rd[D_ITERS];
   unsigned xmask = 0, dmask = 0;
 
-  auto load_half = [&](int pt) {
+  auto load_half = [&](auto pt) __attribute__((always_inline)) {      // (generic: only instantiated where used, i.e. for FAST = false)
     const int tx = pt % P.tilesX;
     const int t2 = pt / P.tilesX;
     const int bb = t2 / P.tilesY;
@@ -763,7 +788,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
     static_for<0, X_ITERS>([&](auto I) {
       constexpr int it = decltype(I)::value;
       const int ul = tg + it * GT;
-      const int hp = (grp * Cfg::XH_UNITS + ul) / XQ;
+      const int hp = (hg * Cfg::XH_UNITS + ul) / XQ;
       const int hy = hp / HWd, hx = hp - hy * HWd;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
       const unsigned ok = unsigned(ul < Cfg::XH_UNITS) & unsigned((unsigned)iy < (unsigned)P.H) &
@@ -775,7 +800,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
     static_for<0, D_ITERS>([&](auto I) {
       constexpr int it = decltype(I)::value;
       const int ul = tg + it * GT;
-      const int p = (grp * Cfg::DH_UNITS + ul) / DQ;
+      const int p = (hg * Cfg::DH_UNITS + ul) / DQ;
       const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
       const unsigned ok = unsigned(ul < Cfg::DH_UNITS) & unsigned(oy < P.H) & unsigned(ox < P.W);
       dmask |= ok << it;
@@ -783,7 +808,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
       rd[it] = *reinterpret_cast<const uint4*>(P.dy + (int64_t)pix * P.Cout + dcc);
     });
   };
-  auto store_half = [&](bf16_t* sX) {
+  auto store_half = [&](auto* sX) __attribute__((always_inline)) {
     bf16_t* sD = sX + NHP * RSX;
     float4 av0, av1, bv0, bv1;
     if (xbn) {
@@ -802,7 +827,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
         if (xbn) v = bn_relu_pack8(v, av0, av1, bv0, bv1);
         const bool keep = xval && ((xmask >> it) & 1u);
         v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
-        const int hp = (grp * Cfg::XH_UNITS + ul) / XQ;
+        const int hp = (hg * Cfg::XH_UNITS + ul) / XQ;
         *reinterpret_cast<uint4*>(sX + hp * RSX + 8 * (xq ^ ((hp & 3) << 2))) = v;
       }
     });
@@ -813,35 +838,165 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
         uint4 v = rd[it];
         const bool keep = dval && ((dmask >> it) & 1u);
         v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
-        const int p = (grp * Cfg::DH_UNITS + ul) / DQ;
+        const int p = (hg * Cfg::DH_UNITS + ul) / DQ;
         *reinterpret_cast<uint4*>(sD + p * RSD + 8 * (dq ^ (((p >> 1) & 1) << 2))) = v;
       }
     });
   };
-  auto mfma_stage = [&](const bf16_t* sX) {
-    const bf16_t* sD = sX + NHP * RSX;
-    frag8_t Af[2], Bf[4];
-    auto loadA = [&](auto Sc) {
-      constexpr int st = decltype(Sc)::value, hr = st / 3, dx = st % 3, c = hr * HWd + dx;
-      const bf16_t* ad = sX + c * RSX + aoff[c & 3];
-      Af[st & 1] = tr_frag(ad, ad + 4 * RSX);
-    };
-    auto loadB = [&](auto Rc) {
-      constexpr int r = decltype(Rc)::value;
-      const bf16_t* bd = sD + r * 16 * RSD + boff;
-      Bf[r & 3] = tr_frag(bd, bd + 4 * RSD);
-    };
-    loadB(std::integral_constant<int, 0>{});
-    loadA(std::integral_constant<int, 0>{});
-    static_for<0, 3 * (PTH + 2)>([&](auto S) {
+
+  // ---- FAST staging (see the kernel's header comment)
+  constexpr int X_FULL = Cfg::XH_UNITS / GT;                 // slots every thread of the group owns (the last one is partial)
+  unsigned relX[X_ITERS], relD[D_ITERS];                     // byte offsets from the tile's origin pixel (mod 2^32)
+  unsigned mT = 0, mB = 0, mL = 0, mR = 0;                   // bit it: slot it lies in the halo row / column of that side
+  unsigned xbad = 0;                                         // slots of the tile in registers that are outside the image
+  bool xborder = false;                                      // (uniform) ... and whether there is any
+  const unsigned cs2 = (unsigned)xcs * 2u;
+  const char* xb = reinterpret_cast<const char*>(xbase + xcc);
+  const char* db = reinterpret_cast<const char*>(P.dy + dcc);
+  const float relu_floor = (has_bn && !from0) ? __builtin_nanf("") : 0.f;
+  unsigned ldsX0 = 0, ldsD0 = 0;                             // LDS byte offsets of slot 0 inside a buffer
+  uint4 rdf0, rdf1;                                          // the two dy units in flight (named: as an array they went to scratch)
+  if constexpr (FAST) {
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int ul = tg + it * GT;
+      const bool own = ul < Cfg::XH_UNITS;
+      const int hp = (hg * Cfg::XH_UNITS + ul) / XQ;
+      const int hy = hp / HWd, hx = hp - hy * HWd;
+      relX[it] = own ? (unsigned)(((hy - 1) * P.W + (hx - 1)) * (int)cs2) : 0u;     // not owned: the origin pixel, never stored
+      mT |= (own && hy == 0) ? (1u << it) : 0u;  mB |= (own && hy == PTH + 1) ? (1u << it) : 0u;
+      mL |= (own && hx == 0) ? (1u << it) : 0u;  mR |= (own && hx == HWd - 1) ? (1u << it) : 0u;
+    });
+    static_for<0, D_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      const int p = (hg * Cfg::DH_UNITS + tg + it * GT) / DQ;
+      relD[it] = (unsigned)(((p >> 4) * P.W + (p & 15)) * P.Cout * 2);
+    });
+    const int hp0 = (hg * Cfg::XH_UNITS + tg) / XQ;         // slot it: halo pixel hp0 + 16 it, same swizzle
+    ldsX0 = (unsigned)(hp0 * RSX + 8 * (xq ^ ((hp0 & 3) << 2))) * 2u;
+    const int p0 = (hg * Cfg::DH_UNITS + tg) / DQ;          // slot it: pixel p0 + 32 it, same swizzle
+    ldsD0 = (unsigned)((NHP * RSX) + p0 * RSD + 8 * (dq ^ (((p0 >> 1) & 1) << 2))) * 2u;
+  }
+  auto load_half_fast = [&](int pt) __attribute__((always_inline)) {                        // pt uniform
+    const int t2 = fast_div(pt, P.tilesX, P.rcp_tilesX);
+    const int tx = pt - t2 * P.tilesX;
+    const int bb = fast_div(t2, P.tilesY, P.rcp_tilesY);
+    const int y0 = (t2 - bb * P.tilesY) * PTH, x0 = tx * Cfg::PTW;
+    const unsigned tile_pix = (unsigned)((bb * P.H + y0) * P.W + x0);
+    const unsigned ft = y0 == 0 ? ~0u : 0u, fb = y0 + PTH == P.H ? ~0u : 0u;
+    const unsigned fl = x0 == 0 ? ~0u : 0u, fr = x0 + Cfg::PTW == P.W ? ~0u : 0u;
+    xborder = (ft | fb | fl | fr) != 0u;
+    xbad = (mT & ft) | (mB & fb) | (mL & fl) | (mR & fr);
+    const unsigned tX = (tile_pix & 0xffffffu) * (cs2 & 0xffffffu);                // v_mul_u32_u24 (eligibility: < 2^24 each)
+    const char* dbt = db + (size_t)tile_pix * (size_t)(P.Cout * 2);                // uniform
+    if (xborder) {
+      const unsigned good = ~xbad;
+      static_for<0, X_ITERS>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)good, it, 1);      // bit it -> 0 / 0xffffffff
+        rx[it] = *reinterpret_cast<const uint4*>(xb + (tX + (relX[it] & m)));      // off the image: the origin pixel
+      });
+    } else {
+      static_for<0, X_ITERS>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        rx[it] = *reinterpret_cast<const uint4*>(xb + (tX + relX[it]));
+      });
+    }
+    static_assert(D_ITERS == 2, "two dy units per thread and stage");
+    rdf0 = *reinterpret_cast<const uint4*>(dbt + relD[0]);
+    rdf1 = *reinterpret_cast<const uint4*>(dbt + relD[1]);
+  };
+  auto store_half_fast = [&](bf16_t* sXb, auto Mc, auto Bc) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(Mc)::value, BNR = decltype(Bc)::value;
+    unsigned char* lx = reinterpret_cast<unsigned char*>(sXb) + ldsX0;
+    unsigned char* ld = reinterpret_cast<unsigned char*>(sXb) + ldsD0;
+    float4 av0, av1, bv0, bv1;
+    if constexpr (BNR) {
+      av0 = *reinterpret_cast<const float4*>(sAB + 8 * xq);
+      av1 = *reinterpret_cast<const float4*>(sAB + 8 * xq + 4);
+      bv0 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq);
+      bv1 = *reinterpret_cast<const float4*>(sAB + CI_T + 8 * xq + 4);
+    }
+    const unsigned good = ~xbad;
+    static_for<0, X_ITERS>([&](auto I) {
+      constexpr int it = decltype(I)::value;
+      if (it < X_FULL || tg + it * GT < Cfg::XH_UNITS) {
+        uint4 v = rx[it];
+        if constexpr (BNR) {
+          auto act = [&](unsigned w, float a_lo, float a_hi, float b_lo, float b_hi) {
+            const float lo = __builtin_fmaxf(fmaf(a_lo, e2f_lo(w), b_lo), relu_floor);
+            const float hi = __builtin_fmaxf(fmaf(a_hi, e2f_hi(w), b_hi), relu_floor);
+            return pack_e2(f32x2{lo, hi});
+          };
+          v.x = act(v.x, av0.x, av0.y, bv0.x, bv0.y); v.y = act(v.y, av0.z, av0.w, bv0.z, bv0.w);
+          v.z = act(v.z, av1.x, av1.y, bv1.x, bv1.y); v.w = act(v.w, av1.z, av1.w, bv1.z, bv1.w);
+        }
+        if constexpr (MASKED) {
+          const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)good, it, 1);
+          v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+        }
+        *reinterpret_cast<uint4*>(lx + it * (16 * RSX * 2)) = v;
+      }
+    });
+    *reinterpret_cast<uint4*>(ld) = rdf0;
+    *reinterpret_cast<uint4*>(ld + 32 * RSD * 2) = rdf1;
+  };
+  auto load_half_any = [&](int pt) __attribute__((always_inline)) {
+    if constexpr (FAST) load_half_fast(pt); else load_half(pt);
+  };
+  auto store_half_any = [&](bf16_t* sXb) __attribute__((always_inline)) {
+    if constexpr (FAST) {
+      if (xborder) { if (has_bn) store_half_fast(sXb, std::true_type{}, std::true_type{}); else store_half_fast(sXb, std::true_type{}, std::false_type{}); }
+      else { if (has_bn) store_half_fast(sXb, std::false_type{}, std::true_type{}); else store_half_fast(sXb, std::false_type{}, std::false_type{}); }
+    } else {
+      store_half(sXb);
+    }
+  };
+  // x fragments: a ring APD steps ahead of the MFMAs (depths 1-3 measured the same once the first fragments are in flight
+  // before the phase starts)
+#ifndef FU_WGRAD_APD
+#define FU_WGRAD_APD 2
+#endif
+  constexpr int APD = FU_WGRAD_APD, NA = APD + 1, NST = 3 * (PTH + 2);
+  static_assert(APD <= 3, "the fragments requested ahead of the barrier must lie in halo row 0");
+  frag8_t Af[NA], Bf[4];
+  // fragment addresses = one lane base per (buffer, row residue) + an immediate (ds offsets reach 64 KB, a buffer is 62.5 KB:
+  // the second buffer gets its own bases; they are opaque to the compiler, which otherwise materialises base + constant
+  // per fragment as loop invariants and spills them)
+  int aoffp[2][4], boffp[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    aoffp[0][j] = aoff[j];
+    aoffp[1][j] = aoff[j] + Cfg::BUF_ELEMS;
+    asm volatile("" : "+v"(aoffp[0][j]), "+v"(aoffp[1][j]));
+  }
+  boffp[0] = boff + NHP * RSX;
+  boffp[1] = boff + NHP * RSX + Cfg::BUF_ELEMS;
+  asm volatile("" : "+v"(boffp[0]), "+v"(boffp[1]));
+  auto loadA = [&](auto Par, auto Sc) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value, st = decltype(Sc)::value, hr = st / 3, dx = st % 3, c = hr * HWd + dx;
+    const bf16_t* ad = sBuf + aoffp[par][c & 3] + c * RSX;
+    Af[st % NA] = tr_frag(ad, ad + 4 * RSX);
+  };
+  auto loadB = [&](auto Par, auto Rc) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value, r = decltype(Rc)::value;
+    const bf16_t* bd = sBuf + boffp[par] + r * 16 * RSD;
+    Bf[r & 3] = tr_frag(bd, bd + 4 * RSD);
+  };
+  auto mfma_prefetch = [&](auto Par) __attribute__((always_inline)) {   // row 0 of x and of dy: staged by the other group (see hg)
+    loadB(Par, std::integral_constant<int, 0>{});
+    static_for<0, APD>([&](auto Sc) { loadA(Par, Sc); });
+  };
+  auto mfma_stage = [&](auto Par) __attribute__((always_inline)) {      // after mfma_prefetch(Par)
+    static_for<0, NST>([&](auto S) {
       constexpr int st = decltype(S)::value, hr = st / 3, dx = st % 3;
-      if constexpr (st + 1 < 3 * (PTH + 2)) loadA(std::integral_constant<int, st + 1>{});
-      if constexpr (dx == 0 && hr + 1 < PTH) loadB(std::integral_constant<int, hr + 1>{});
+      if constexpr (st + APD < NST) loadA(Par, std::integral_constant<int, st + APD>{});
+      if constexpr (dx == 0 && hr + 1 < PTH) loadB(Par, std::integral_constant<int, hr + 1>{});
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, 3>([&](auto DY) {
         constexpr int dy = decltype(DY)::value, r = hr - dy;
         if constexpr (r >= 0 && r < PTH)
-          acc[dy * 3 + dx] = FU_MFMA32(Af[st & 1], Bf[r & 3], acc[dy * 3 + dx]);
+          acc[dy * 3 + dx] = FU_MFMA32(Af[st % NA], Bf[r & 3], acc[dy * 3 + dx]);
       });
     });
   };
@@ -853,73 +1008,91 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   bf16_t* buf0 = sBuf;
   bf16_t* buf1 = sBuf + Cfg::BUF_ELEMS;
   __syncthreads();                               // sAB
-  load_half(pt0);
-  store_half(buf0);
-  load_half(min(pt0 + 1, pt1 - 1));
+  load_half_any(pt0);
+  store_half_any(buf0);
+  load_half_any(min(pt0 + 1, pt1 - 1));
   __syncthreads();                               // stage 0 complete
   if (grp) {                                     // group 1 runs half a stage ahead with its staging
-    store_half(buf1);
-    load_half(min(pt0 + 2, pt1 - 1));
+    store_half_any(buf1);
+    load_half_any(min(pt0 + 2, pt1 - 1));
     __syncthreads();
   }
 #ifdef FU_CONV_STAMPS
-  unsigned long long tM = 0, tB1 = 0, tSt = 0, tLd = 0, tB2 = 0, tStart = __builtin_amdgcn_s_memtime();
+  unsigned long long tM = 0, tB1 = 0, tSt = 0, tLd = 0, tB2 = 0, tGap = 0, sPrev = 0;
 #endif
-  for (int n = 0; n < T; ++n) {
+  // The loop is unrolled by the buffer parity: with `(n & 1) ? buf1 : buf0` every LDS address of the MFMA phase existed in
+  // two variants that hipcc kept in spilled SGPRs and selected at the top of each iteration -- 60 scalar instructions between
+  // the barrier and the first fragment read.
+  bf16_t* const sbuf0 = grp ? buf0 : buf1;       // where this wave stages while it multiplies an even stage: stage n+1+grp
+  bf16_t* const sbuf1 = grp ? buf1 : buf0;
+  mfma_prefetch(std::integral_constant<int, 0>{});
+  auto body = [&](auto Par, int n) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value;
 #ifdef FU_CONV_STAMPS
     const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-    mfma_stage((n & 1) ? buf1 : buf0);
+    mfma_stage(Par);
 #ifdef FU_CONV_STAMPS
     const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
 #ifdef FU_CONV_STAMPS
     const unsigned long long s2 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long s2b = __builtin_amdgcn_s_memtime();
 #endif
     // stage n+1+grp (already in registers) -> the other buffer of that stage's parity; past the last stage this stores a
     // copy of the last tile into a buffer nobody reads any more (unconditional on purpose: conditional loads become
     // phis that hipcc waits for in front of the MFMA block)
-    store_half(((n + 1 + grp) & 1) ? buf1 : buf0);
+    // (measured and dropped, twice: storing slot by slot with the next tile's load of the same slot issued in between -- the
+    //  texture path takes ~45 cycles per 1 KB wave load, 1250 cycles for the eight of a thread -- and a raised s_setprio for
+    //  the staging group.  The staging phase shrinks by a third in the stamps; the kernel gets 2-3 % SLOWER, one register
+    //  spill included.)
+    store_half_any(par ? sbuf1 : sbuf0);
 #ifdef FU_CONV_STAMPS
     const unsigned long long s3 = __builtin_amdgcn_s_memtime();
 #endif
-    load_half(min(pt0 + n + 2 + grp, pt1 - 1));
+    load_half_any(min(pt0 + n + 2 + grp, pt1 - 1));
+    mfma_prefetch(std::integral_constant<int, 1 - par>{});   // (past the last stage: reads of a valid buffer, never used)
 #ifdef FU_CONV_STAMPS
     const unsigned long long s4 = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
 #ifdef FU_CONV_STAMPS
     const unsigned long long s5 = __builtin_amdgcn_s_memtime();
-    if (n > 0) { tM += s1 - s0; tB1 += s2 - s1; tSt += s3 - s2b; tLd += s4 - s3; tB2 += s5 - s4; tStart += 0; }
-    if (n == 0) tStart = s2b - s2;   // (load wait sample)
+    if (n > 0) { tM += s1 - s0; tB1 += s2 - s1; tSt += s3 - s2; tLd += s4 - s3; tB2 += s5 - s4; tGap += s0 - sPrev; }
+    sPrev = s5;
 #endif
+  };
+  for (int n = 0; n < T; n += 2) {
+    body(std::integral_constant<int, 0>{}, n);
+    if (n + 1 >= T) break;
+    body(std::integral_constant<int, 1>{}, n + 1);
   }
   if (!grp) __syncthreads();                     // group 1's pre-loop barrier
 #ifdef FU_CONV_STAMPS
   if (P.dbg && lane == 0 && blockIdx.x < 256) {
     unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
-    d[0] = tM; d[1] = tB1; d[2] = tSt; d[3] = (unsigned long long)max(T - 1, 0); d[4] = tLd; d[5] = tB2; d[6] = tStart; d[7] = 0;
+    d[0] = tM; d[1] = tB1; d[2] = tSt; d[3] = (unsigned long long)max(T - 1, 0); d[4] = tLd; d[5] = tB2; d[6] = tGap; d[7] = 0;
   }
 #endif
 
-  const int co = co0 + ni * 32 + l31;
+  const int co = co0 + ni * 32 + l31;             // slab[split][tap][Cin / 4][Cout][4], as in k_wgrad_bf16
   if (co < P.Cout) {
+    const int cq = P.Cin >> 2;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < P.Cin) P.slab[(((int64_t)split * 9 + tap) * P.Cin + ci) * P.Cout + co] = acc[tap][r];
+      for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + mi * 32 + 8 * j + 4 * lh;
+        if (ci < P.Cin)
+          *reinterpret_cast<float4*>(P.slab + ((((int64_t)split * 9 + tap) * cq + (ci >> 2)) * P.Cout + co) * 4) =
+              make_float4(acc[tap][4 * j], acc[tap][4 * j + 1], acc[tap][4 * j + 2], acc[tap][4 * j + 3]);
       }
     }
   }
 }
 
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
-                        int ndb, float* db, hipStream_t s);
+                        int ndb, float* db, hipStream_t s, bool ci4);
 
 template <int WMI, int PTH, int TAPS = 9>
 static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
@@ -952,7 +1125,7 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
 #define FU_WGRAD_LOCKSTEP_DEFAULT 0   // A/B builds: -DFU_WGRAD_LOCKSTEP_DEFAULT=1
 #endif
 #if !FU_HALF
-int g_wgrad_force_lockstep = FU_WGRAD_LOCKSTEP_DEFAULT;   // testing hook (fu_test_force_lockstep_wgrad): k_wgrad_bf16<4,8> instead of the ping-pong kernel
+int g_wgrad_force_lockstep = FU_WGRAD_LOCKSTEP_DEFAULT;   // testing hook (fu_test_force_lockstep_wgrad): 1 = k_wgrad_bf16<4,8> instead of the ping-pong kernel, 2 = the ping-pong kernel with its general staging
 #endif
 
 static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
@@ -966,16 +1139,26 @@ static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
   if (S < 1) S = 1;
   P.perSplit = ceil_div(P.nPix, S);
   P.S = ceil_div(P.nPix, P.perSplit);     // every split owns at least one stage
+  P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
   static bool attr_set = false;
   if (!attr_set) {
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16_pp),
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16_pp<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16_pp<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
+  // whole pixel tiles, whole channel tiles, 24-bit pixel indices and pixel strides, 32-bit byte offsets inside a source
+  const int64_t npx = (int64_t)P.B * P.H * P.W;
+  const int cmax = P.C0 > P.C1 ? P.C0 : P.C1;
+  const bool fast = g_wgrad_force_lockstep != 2 && P.H % Cfg::PTH == 0 && P.W % Cfg::PTW == 0 && P.Cin % Cfg::CI_T == 0 &&
+                    P.Cout % Cfg::CO_T == 0 && npx < (1 << 24) && npx * cmax * 2 < (int64_t(1) << 32) &&
+                    npx * P.Cout * 2 < (int64_t(1) << 32) && (int64_t)P.nPix * nT < (int64_t(1) << 31);
   const ProfSlot ps = g_prof_slot;
   g_prof_slot = ProfSlot();
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  hipLaunchKernelGGL(k_wgrad_bf16_pp, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  if (fast) hipLaunchKernelGGL(k_wgrad_bf16_pp<true>, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  else hipLaunchKernelGGL(k_wgrad_bf16_pp<false>, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;
@@ -1007,11 +1190,11 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   // over the ping-pong one; the eight unwritten tap slabs reach only taps of dw_oihw that the caller never reads
   if (in.center_only && !g_bf16_force_full_taps && P.Cin > 64) st = launch_wgrad_cfg<4, 8, 1>(P, 256, s);
   else if (in.center_only && !g_bf16_force_full_taps) st = launch_wgrad_cfg<2, 8, 1>(P, 512, s);
-  else if (P.Cin > 64 && !g_wgrad_force_lockstep) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
   else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);
   else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;
-  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
+  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s, true);
 }
 
 }  // namespace fu

@@ -484,6 +484,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // packed [tap][Cin][Cout] (slab 0 after the reduce) -> dw OIHW [Cout][cin_real][9].
 // block tile: 32 co x 8 ci x 9 taps through LDS: 128-byte reads along co, 288-byte writes along (ci, tap).
+// CI4: the 16-bit weight-gradient kernels write their slabs as [tap][Cin / 4][Cout][4] -- a lane of the 32x32 accumulator
+// tile holds four consecutive c_in of one c_out, so each lane stores 16 bytes and a wave 512 contiguous bytes (with
+// [tap][Cin][Cout] the epilogue was 144 four-byte stores per thread, issue-bound on the texture path).
+template <bool CI4>
 __global__ __launch_bounds__(256) void k_wgrad_transpose(const float* __restrict__ packed, int Cin, int Cout,
                                                          int cin_real, float* __restrict__ dw,
                                                          const float* __restrict__ unscale) {
@@ -492,9 +496,16 @@ __global__ __launch_bounds__(256) void k_wgrad_transpose(const float* __restrict
   const int nCo = (Cout + 31) / 32;
   const int co0 = (blockIdx.x % nCo) * 32, ci0 = (blockIdx.x / nCo) * 8;
   for (int i = threadIdx.x; i < 72 * 32; i += 256) {
-    const int row = i >> 5, c = i & 31;          // row = tap*8 + ci_local
-    const int tap = row >> 3, ci = ci0 + (row & 7), co = co0 + c;
-    t[row][c] = (ci < Cin && co < Cout) ? packed[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
+    if constexpr (CI4) {
+      const int k = i & 3, c = (i >> 2) & 31, q = (i >> 7) & 1, tap = i >> 8;     // 512 contiguous bytes per (tap, quad)
+      const int ci = ci0 + 4 * q + k, co = co0 + c;
+      t[tap * 8 + 4 * q + k][c] =
+          (ci < Cin && co < Cout) ? packed[(((int64_t)tap * (Cin >> 2) + (ci >> 2)) * Cout + co) * 4 + k] : 0.f;
+    } else {
+      const int row = i >> 5, c = i & 31;          // row = tap*8 + ci_local
+      const int tap = row >> 3, ci = ci0 + (row & 7), co = co0 + c;
+      t[row][c] = (ci < Cin && co < Cout) ? packed[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 32 * 72; i += 256) {
@@ -518,14 +529,16 @@ static int launch_wgrad_reduce_sl(const float* slab, int S, int Cin, int Cout, i
 }
 
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
-                        int ndb, float* db, hipStream_t s) {
+                        int ndb, float* db, hipStream_t s, bool ci4) {
+  FU_REQUIRE(!ci4 || Cin % 4 == 0, "wgrad_reduce: the interleaved slab layout needs c_in %% 4 == 0");
   int st;
   if (S >= 64) st = launch_wgrad_reduce_sl<16>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
   else if (S >= 16) st = launch_wgrad_reduce_sl<4>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
   else st = launch_wgrad_reduce_sl<1>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
   if (st) return st;
   const int blocks = ceil_div(Cout, 32) * ceil_div(Cin, 8);
-  hipLaunchKernelGGL(k_wgrad_transpose, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw, g_grad_unscale);
+  if (ci4) hipLaunchKernelGGL(k_wgrad_transpose<true>, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw, g_grad_unscale);
+  else hipLaunchKernelGGL(k_wgrad_transpose<false>, dim3(blocks), dim3(256), 0, s, slab, Cin, Cout, cin_real, dw, g_grad_unscale);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -568,7 +581,7 @@ int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float*
   hipLaunchKernelGGL(k_wgrad_f32, dim3(grid), dim3(256), sh, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
-  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s);
+  return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s, false);
 }
 
 }  // namespace fu

@@ -242,8 +242,9 @@ int fu_profile_read(fu_ctx* ctx, int kernel_class, int64_t* launches, double* to
 /* Testing hook: on != 0 makes every bf16 3x3 convolution (forward / dgrad) run on the general kernel even when the
  * shape is eligible for the aligned-shape fast kernel, so that the parity tests can cover both.  Process-wide. */
 void fu_test_force_general_conv(int on);
-/* Testing hook: on != 0 runs the bf16 weight gradient of c_in > 64 on the lock-step kernel k_wgrad_bf16<4,8> instead of
- * the ping-pong kernel k_wgrad_bf16_pp (same accumulation order: the results are bit-identical).  Process-wide. */
+/* Testing hook: on = 1 runs the bf16 weight gradient of c_in > 64 on the lock-step kernel k_wgrad_bf16<4,8> instead of
+ * the ping-pong kernel k_wgrad_bf16_pp, on = 2 keeps the ping-pong kernel but with its general (any-shape) staging where
+ * the whole-tile staging would be chosen (same accumulation order: all three are bit-identical).  Process-wide. */
 void fu_test_force_lockstep_wgrad(int on);
 /* Testing hook: workgroup tile of the aligned-shape bf16 conv kernel at 64 output channels: 0 = heuristic (default),
  * 1 = never the tall 16x32-pixel tile (nor the row-stationary kernel), 2 = the tall tile wherever 64-channel tiles run,

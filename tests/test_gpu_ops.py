@@ -279,8 +279,12 @@ def wgrad_path(request):
 
 @pytest.mark.parametrize("shape", [(2, 128, 64, 64, 40, 24, True), (1, 96, 0, 32, 16, 16, False),
                                    (16, 128, 0, 128, 32, 32, True), (3, 256, 0, 72, 19, 50, True),
-                                   (1, 128, 128, 64, 8, 16, True)])
+                                   (1, 128, 128, 64, 8, 16, True), (2, 64, 64, 64, 32, 64, True),
+                                   (2, 256, 0, 128, 32, 64, False), (1, 128, 0, 64, 24, 48, True),
+                                   (3, 64, 192, 64, 16, 16, True)])
 def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape, lowp):
+    """Three routes to the same sums: ping-pong kernel with whole-tile staging (where eligible), ping-pong kernel with the
+    general staging, lock-step kernel.  Shapes cover interior and border tiles, a channel tile straddling two sources, no BN."""
     B, C0, C1, Cout, H, W, bn = shape
     lib = _lib.load()
     x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=5)
@@ -289,7 +293,7 @@ def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape, lowp):
     d0, d1 = nhwc_bf(x0), (nhwc_bf(x1) if x1 is not None else None)
     da, db = (a.to(DEV), b.to(DEV)) if bn else (None, None)
     outs = []
-    for lock in (0, 1):
+    for lock in (0, 1, 2):
         lib.fu_test_force_lockstep_wgrad(lock)
         dw = torch.full(w.shape, float("nan"), device=DEV)
         try:
@@ -300,7 +304,7 @@ def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape, lowp):
             lib.fu_test_force_lockstep_wgrad(0)
         outs.append(dw.cpu())
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("shape", BF_SHAPES)

@@ -20,6 +20,6 @@ def run(B, C0, Cout, H, W):
     for w in range(8):
         v = d[:, w]; v = v[v[:, 3] > 0]; n = v[:, 3]
         m = lambda k: np.median(v[:, k] / n)
-        print(f"   wave {w}: mfma {m(0):.0f} | barrier1 {m(1):.0f} | bn+store {m(2):.0f} | load issue {m(4):.0f} | barrier2 {m(5):.0f} | sum {m(0)+m(1)+m(2)+m(4)+m(5):.0f}   (first load wait {np.median(v[:,6]):.0f})")
-run(16, 128, 128, 128, 128)
-run(16, 512, 512, 32, 32)
+        print(f"   wave {w}: mfma {m(0):.0f} | barrier1 {m(1):.0f} | bn+store {m(2):.0f} | load issue + prefetch {m(4):.0f} | barrier2 {m(5):.0f} | sum {m(0)+m(1)+m(2)+m(4)+m(5):.0f}   | loop gap {m(6):.0f} | period {m(0)+m(1)+m(2)+m(4)+m(5)+m(6):.0f}")
+for shp in [(16, 128, 128, 128, 128), (16, 512, 512, 32, 32), (16, 256, 256, 64, 64)]:
+    run(*shp)
