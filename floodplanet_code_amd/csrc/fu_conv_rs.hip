@@ -115,10 +115,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   auto dma_weights = [&](int k0) {
     // uniform base (SGPR pair) + one 32-bit lane offset: nine per-tap 64-bit lane addresses would be hoisted out of the
     // chunk loop and cost 18 registers
+    // (the lane offset is made opaque per call: as a loop invariant hipcc re-associates the sum into nine hoisted 64-bit
+    //  lane addresses + k0 after all -- three of them were spilled, and each reload sat behind an s_waitcnt vmcnt(0) in the
+    //  middle of the nine DMA issues, i.e. waited for the pieces already in flight.  Opaque: 256 registers and NO spill at
+    //  ROWS 8 (11 before), 158 at ROWS 4; conv class 2.69 -> 2.62 ms per step, one stream, same box)
     const char* ub = reinterpret_cast<const char*>(P.wpk) + (size_t)k0 * 2;
+    unsigned ws = w_src;
+    asm volatile("" : "+v"(ws));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + (size_t)tap * w_tap + (size_t)w_src),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + (size_t)tap * w_tap + (size_t)ws),
                                        (__attribute__((address_space(3))) void*)(sW + tap * (BN * ROWB) + wm * 1024), 16, 0, 0);
   };
 
@@ -205,6 +211,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
 
   // One chunk: for each column shift dx and subtile pair sp, the six weight fragments (3 kernel rows x 2 subtiles) stay
   // in registers while the ten input rows stream past; input row ri feeds output rows ri - dy.
+  // (Measured and dropped: the six blocks as ONE software pipeline of 6 x IN_ROWS steps -- pixel ring running on across the
+  //  block boundary, the next block's weight fragments read into the registers of the kernel rows that have just died -- so
+  //  that no block starts with a burst of ten fragment reads behind an lgkmcnt(0).  Same registers, no spill, bit-identical:
+  //  conv class 2624 -> 2629-2636 us per step.  The bubbles are covered by the co-resident workgroup.)
   auto mfma_block = [&](auto Lc) {
     constexpr bool LOADS = decltype(Lc)::value;     // issue the next chunk's activation loads behind the MFMAs
     static_for<0, 6>([&](auto Dc) {
