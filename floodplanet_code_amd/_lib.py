@@ -87,6 +87,7 @@ SIGNATURES = {
     "fu_test_force_general_conv": (None, [_i]),
     "fu_test_force_lockstep_wgrad": (None, [_i]),
     "fu_test_conv_tile_mode": (None, [_i]),
+    "fu_test_bnb_separate": (None, [_i]),
     "fu_test_force_full_taps": (None, [_i]),
     "fu_set_side_stream": (_i, [_p, _i]),
     "fu_backward_join": (_i, [_p, _p]),

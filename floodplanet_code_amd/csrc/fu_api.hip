@@ -194,6 +194,7 @@ struct Conv {
   void* y = nullptr;
   void* gy = nullptr;
   const void* pool_g = nullptr;   // backward: dL/d(maxpool(this output)), to be folded into this conv's BN backward
+  int bnb_tiles = 0;              // backward: > 0 = the producer of gy left this many rows of BN-backward sums in bnb_part
 };
 
 enum BlockKind { BK_INC = 0, BK_DOWN = 1, BK_UP = 2 };
@@ -302,6 +303,7 @@ struct fu_ctx {
   float* dlogits = nullptr;
   float* stats = nullptr;
   float* bnb_part = nullptr;
+  int64_t bnb_cap = 0;         // floats
   float* db_part = nullptr;
   float* db_part2 = nullptr;      // second bias-gradient partial buffer (side-stream wgrad, alternating per conv)
   hipStream_t side = nullptr;     // side stream for the weight-gradient chain (wgrad + slab reduce + transpose)
@@ -554,6 +556,7 @@ int alloc_workspace(fu_ctx* c) {
   A.want(&c->dlogits, npix0 * f.n_classes * sizeof(float));
   A.want(&c->stats, max_stats * sizeof(float));
   A.want(&c->bnb_part, max_bnb * sizeof(float));
+  c->bnb_cap = max_bnb;
   A.want(&c->db_part, max_dbp * sizeof(float));
   A.want(&c->db_part2, max_dbp * sizeof(float));
   A.want(&c->dscratch, reduce_scratch_elems(std::max(max_c, 64)) * sizeof(double));
@@ -784,6 +787,10 @@ int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_
   return 0;
 }
 
+// testing hook (fu_test_bnb_separate) and A/B switch (environment FU_BNB_SEPARATE): 1 = BatchNorm-backward sums always by
+// their own reduce pass, never from the producer of the gradient (BnbFuse, fu_common.h)
+static int g_bnb_separate = getenv("FU_BNB_SEPARATE") != nullptr ? 1 : 0;
+
 int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   Block& K = c->blk[i];
   Conv& v = K.c[j];
@@ -801,8 +808,9 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   float* dbp = (side && par) ? c->db_part2 : c->db_part;
   if (side && c->wg_pending[par]) FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_wg[par], 0));   // buffer free again
   FU_TRY(launch_bn_bwd(c->prec, v.gy, v.y, v.cout, npix, v.a, v.b, v.mean, v.invstd, P(c, v.p_g), G(c, v.p_g),
-                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s, v.pool_g, B, H, W));
+                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s, v.pool_g, B, H, W, v.bnb_tiles));
   v.pool_g = nullptr;
+  v.bnb_tiles = 0;
   // weight (and bias) gradient
   const ConvIn in = conv_input(c, i, j);
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
@@ -823,9 +831,22 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   // data gradient
   if (!(K.role == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
   if (j == 1) {
+    // this dgrad's destination is dL/d relu(bn(y)) of the block's first conv: a kernel that can (the row-stationary 16-bit
+    // one) also leaves that BatchNorm's backward sums in bnb_part, consumed by the very next launch_bn_bwd on this stream
+    Conv& v0 = K.c[0];
+    const bool separate = g_bnb_separate != 0;      // testing hook / FU_BNB_SEPARATE: always the separate reduce pass
+    int tiles = 0;
+    if (c->prec != PREC_F32 && !c->sync.hook && !separate) {
+      BnbFuse f;
+      f.y = v0.y; f.a = v0.a; f.b = v0.b; f.mean = v0.mean; f.invstd = v0.invstd;
+      f.part = c->bnb_part; f.max_elems = c->bnb_cap; f.tiles_out = &tiles;
+      g_bnb_fuse = f;
+    }
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
-    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.c[0].gy, K.c[0].cout, nullptr, 0, nullptr, nullptr, B, H, W,
-                          s));
+    const int st = launch_conv3x3(c->prec, din, v.wd, nullptr, v0.gy, v0.cout, nullptr, 0, nullptr, nullptr, B, H, W, s);
+    g_bnb_fuse = BnbFuse();
+    if (st) return st;
+    v0.bnb_tiles = tiles;
   } else if (K.kind == BK_DOWN) {
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.g_pooled, v.cin_real, nullptr, 0, nullptr, nullptr, B, H, W,
@@ -885,8 +906,18 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
     if (c->prec == PREC_F16)      // fp16 gradient maps: power-of-two loss scale from max|dL/dlogits| (UnscaleScope removes it)
       FU_TRY(launch_loss_scale(c->dlogits, (int64_t)B * f.height * f.width * f.n_classes, c->ce_part, c->loss_scale, s));
     Conv& last = c->blk[c->nb - 1].c[1];
+    // the head's data gradient is dL/d relu(bn(y)) of the last conv: it can leave that BatchNorm's backward sums behind
+    BnbFuse fz;
+    int tiles = 0;
+    const bool want = c->prec != PREC_F32 && !c->sync.hook && !g_bnb_separate;
+    if (want) {
+      fz.y = last.y; fz.a = last.a; fz.b = last.b; fz.mean = last.mean; fz.invstd = last.invstd;
+      fz.part = c->bnb_part; fz.max_elems = c->bnb_cap; fz.tiles_out = &tiles;
+    }
     FU_TRY(launch_head_bwd(c->prec, c->dlogits, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
-                           (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s));
+                           (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s,
+                           want ? &fz : nullptr));
+    last.bnb_tiles = tiles;
     return 0;
   }
   if (c->fusion && block == 5) {
@@ -1415,3 +1446,5 @@ int fu_op_upsample2(int precision, const void* src, const float* bn_a, const flo
 }
 
 }  // extern "C"
+
+extern "C" void fu_test_bnb_separate(int on) { g_bnb_separate = on ? 1 : 0; }

@@ -214,6 +214,21 @@ static inline int sync_world() { return (g_sync && g_sync->hook) ? g_sync->world
 // flat gradient buffer always holds true gradients.  The API layer points g_grad_unscale at scale + 1 for the duration of
 // a backward call in fp16 mode; nullptr (fp32 / bf16) means 1.
 extern thread_local const float* g_grad_unscale;
+
+// BatchNorm-backward sums from the PRODUCER of dL/dz (round 2): a dgrad launch whose single destination g = dL/d relu(bn(y))
+// feeds a BatchNorm backward can emit that backward's two sums (sum g*m, sum g*m*xhat, m = [a*y + b > 0]) per workgroup
+// tile from its epilogue, where g is still in registers -- k_bn_bwd_reduce (one read of g and one of y, 14 launches per
+// step) then disappears for that layer.  The API layer fills this request right before launch_conv3x3 and clears it after;
+// a kernel that honours it (the row-stationary 16-bit kernel, single destination, <= max_tiles workgroup tiles) writes
+// part[tile][channel][2] and *tiles_out = number of tiles; everything else leaves *tiles_out untouched (0 = not fused).
+struct BnbFuse {
+  const void* y = nullptr;                 // raw conv output of the BatchNorm, NHWC, the destination's shape
+  const float *a = nullptr, *b = nullptr, *mean = nullptr, *invstd = nullptr;
+  float* part = nullptr;
+  int64_t max_elems = 0;                   // capacity of part (floats)
+  int* tiles_out = nullptr;
+};
+extern thread_local BnbFuse g_bnb_fuse;
 int launch_loss_scale(float* dlogits, int64_t n, float* partials /* >= 256 floats */, float* scale /* [2] */, hipStream_t s);
 
 // ---- kernel launchers (implemented in the .hip files) ----------------------------------------
@@ -299,7 +314,7 @@ int64_t bn_bwd_partial_elems(int C, int64_t npix);
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s, const void* g_pool = nullptr, int B = 0, int H = 0, int W = 0);
+                  hipStream_t s, const void* g_pool = nullptr, int B = 0, int H = 0, int W = 0, int ext_partials = 0);
 
 int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                     hipStream_t s);
@@ -357,7 +372,8 @@ int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int
 // head backward: G[y] = dlogits * W ; dW = sum dlogits (x) z ; db = sum dlogits
 int64_t head_bwd_partial_elems(int C, int ncls);
 int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
-                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s);
+                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s,
+                    const BnbFuse* fuse = nullptr);
 
 int launch_stitch_add(const float* logits_nhwc, int ncls, int cropW, float* canvas, float* weight, int canvasW, int h0,
                       int w0, int dh, int dw, hipStream_t s);

@@ -130,6 +130,9 @@ struct BConvP {
   unsigned rcp_nCo;                            // row-stationary kernel: channel tile fastest in the workgroup order
   unsigned long long* dbg;   // optional s_memtime stamps per workgroup (tools/stamp_test.py; FU_CONV_STAMPS builds)
   int center_only;           // 1: every tap but the centre one of wpk is zero (embedded 1x1): the fast kernel skips them
+  // row-stationary kernel, dgrad into a BatchNorm's output gradient (BnbFuse, fu_common.h): the raw conv output y of that
+  // BatchNorm, its a / b / mean / invstd, and the per-tile sums [nPix][N][2]; all null otherwise
+  const bf16_t* bnb_y; const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_invstd; float* bnb_part;
 };
 
 // aligned-shape fast path (fu_conv_bf16_fast.hip)

@@ -381,6 +381,7 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   P.B = B; P.H = H; P.W = W;
   P.dbg = g_conv_dbg;
   P.center_only = (in.center_only && !g_bf16_force_full_taps) ? 1 : 0;
+  P.bnb_y = nullptr; P.bnb_a = P.bnb_b = P.bnb_mean = P.bnb_invstd = nullptr; P.bnb_part = nullptr;
   FU_REQUIRE(P.C0 % 8 == 0 && P.C1 % 8 == 0, "conv3x3_bf16: input channel counts must be multiples of 8 (C0=%d C1=%d)",
              P.C0, P.C1);
   FU_REQUIRE(P.a0 == nullptr || P.C0 <= 1024, "conv3x3_bf16: at most 1024 BN-activated channels in source 0 (got %d)",

@@ -208,6 +208,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   if (has_bn) {
     for (int c = tid; c < P.C0; c += NT) { sAB[c] = P.a0[c]; sAB[512 + c] = P.b0[c]; }
   }
+  const bool bnb = P.bnb_y != nullptr;             // uniform; the launcher guarantees !has_bn, one destination
+  if (bnb && tid < BN) {                           // this tile's 64 channels: a, b, invstd, -mean * invstd
+    const int c = n0 + tid;
+    const float iv = P.bnb_invstd[c];
+    sAB[tid] = P.bnb_a[c]; sAB[64 + tid] = P.bnb_b[c]; sAB[128 + tid] = iv; sAB[192 + tid] = -P.bnb_mean[c] * iv;
+  }
 
   // One chunk: for each column shift dx and subtile pair sp, the six weight fragments (3 kernel rows x 2 subtiles) stay
   // in registers while the ten input rows stream past; input row ri feeds output rows ri - dy.
@@ -326,6 +332,80 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   const bool to0 = n0 < P.D0;                                   // uniform: D0 % 64 == 0 with two destinations
   char* dbase = reinterpret_cast<char*>(to0 ? P.dst0 + n0 : P.dst1 + (n0 - P.D0));
   const int dstride = to0 ? P.D0 : P.D1;
+  // per-channel sums over the tile: 16 lanes (pixels) of a row group, then the 4 waves through LDS; fixed order
+  // DPP only (a __shfl_xor is a ds_bpermute: 128 of them were ~4000 cycles of a 2-chunk tile): row_shr 1, 2, 4, 8
+  // inside the 16-lane rows; lane 15 of every row ends with the row's total
+  auto tile_sums_out = [&](float (&u)[16], float (&q)[16], float* out) __attribute__((always_inline)) {
+    auto row_sum = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+      return v;
+    };
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { u[c] = row_sum(u[c]); q[c] = row_sum(q[c]); }
+    float* red = reinterpret_cast<float*>(smem_raw);            // [4 waves][64 channels][2]
+    __syncthreads();
+    if (lx == 15) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        red[(wm * BN + 16 * lg + c) * 2 + 0] = u[c];
+        red[(wm * BN + 16 * lg + c) * 2 + 1] = q[c];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, t = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { s += red[(m * BN + tid) * 2 + 0]; t += red[(m * BN + tid) * 2 + 1]; }
+      float* o = out + ((int64_t)pixT * P.N + n0 + tid) * 2;
+      o[0] = s;
+      o[1] = t;
+    }
+  };
+  if (bnb) {
+    // BatchNorm-backward sums of the destination (BnbFuse, fu_common.h): g = the accumulators (fp32, before their rounding
+    // to the element type), y = the BatchNorm's raw input at the same pixels and channels.  Channel-group major: the four
+    // coefficients of four channels stay in registers while the rows stream past, all y rows are resident (2 x 16 bytes
+    // per row and lane) -- row major would keep 64 coefficient registers live beside the 128 accumulators.
+    uint4 yr[Cfg::ROWS][2];
+#pragma unroll
+    for (int ro = 0; ro < Cfg::ROWS; ++ro) {
+      const int oy = y0 + wm * Cfg::ROWS + ro, ox = x0 + lx;
+      const char* yp = reinterpret_cast<const char*>(P.bnb_y) +
+                       ((size_t)((bb * P.H + oy) * P.W + ox) * (size_t)P.N + (size_t)(n0 + 16 * lg)) * 2;
+      yr[ro][0] = *reinterpret_cast<const uint4*>(yp);
+      yr[ro][1] = *reinterpret_cast<const uint4*>(yp + 16);
+    }
+    float u[16], q[16];
+    static_for<0, 4>([&](auto Sc) {
+      constexpr int s = decltype(Sc)::value;
+      const float4 ca = *reinterpret_cast<const float4*>(sAB + 16 * lg + 4 * s);
+      const float4 cb = *reinterpret_cast<const float4*>(sAB + 64 + 16 * lg + 4 * s);
+      const float4 ci = *reinterpret_cast<const float4*>(sAB + 128 + 16 * lg + 4 * s);
+      const float4 cm = *reinterpret_cast<const float4*>(sAB + 192 + 16 * lg + 4 * s);
+      float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ro = 0; ro < Cfg::ROWS; ++ro) {
+        const uint4 w4 = yr[ro][s >> 1];
+        const unsigned w01 = (s & 1) ? w4.z : w4.x, w23 = (s & 1) ? w4.w : w4.y;    // channels 4s, 4s+1 | 4s+2, 4s+3
+        const float yv[4] = {e2f_lo(w01), e2f_hi(w01), e2f_lo(w23), e2f_hi(w23)};
+        const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w};
+        const float iv[4] = {ci.x, ci.y, ci.z, ci.w}, mv[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gm = fmaf(av[k], yv[k], bv[k]) > 0.f ? acc[ro][s][k] : 0.f;
+          t1[k] += gm;
+          t2[k] = fmaf(gm, fmaf(yv[k], iv[k], mv[k]), t2[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { u[4 * s + k] = t1[k]; q[4 * s + k] = t2[k]; }
+    });
+    tile_sums_out(u, q, P.bnb_part);
+    __syncthreads();                                  // `red` aliases the tile; nothing below reads LDS but sAB
+  }
   float ssum[16], ssq[16], biasv[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; biasv[c] = sAB[1024 + 16 * lg + c]; }
@@ -348,38 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
     *reinterpret_cast<uint4*>(dp) = make_uint4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<uint4*>(dp + 16) = make_uint4(o[4], o[5], o[6], o[7]);
   }
-  if (P.stats) {
-    // per-channel sums over the tile: 16 lanes (pixels) of a row group, then the 4 waves through LDS; fixed order
-    // DPP only (a __shfl_xor is a ds_bpermute: 128 of them were ~4000 cycles of a 2-chunk tile): row_shr 1, 2, 4, 8
-    // inside the 16-lane rows; lane 15 of every row ends with the row's total
-    auto row_sum = [](float v) {
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
-      return v;
-    };
-#pragma unroll
-    for (int c = 0; c < 16; ++c) { ssum[c] = row_sum(ssum[c]); ssq[c] = row_sum(ssq[c]); }
-    float* red = reinterpret_cast<float*>(smem_raw);            // [4 waves][64 channels][2]
-    __syncthreads();
-    if (lx == 15) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        red[(wm * BN + 16 * lg + c) * 2 + 0] = ssum[c];
-        red[(wm * BN + 16 * lg + c) * 2 + 1] = ssq[c];
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { s += red[(m * BN + tid) * 2 + 0]; q += red[(m * BN + tid) * 2 + 1]; }
-      float* o = P.stats + ((int64_t)pixT * P.N + n0 + tid) * 2;
-      o[0] = s;
-      o[1] = q;
-    }
-  }
+  if (P.stats) tile_sums_out(ssum, ssq, P.stats);
 #ifdef FU_CONV_STAMPS
   if (P.dbg && tid == 0) {
     const unsigned long long T2c = __builtin_amdgcn_s_memtime();
@@ -432,7 +481,18 @@ static int launch_rs_cfg(BConvP& P, hipStream_t s) {
 // 16 x 32-pixel tiles where they still give every CU two workgroups, 16 x 16 otherwise
 int launch_conv3x3_rs(BConvP& P, hipStream_t s) {
   const int64_t t512 = (int64_t)P.B * (P.H / 32) * (P.W / 16) * (P.N / 64);
-  if ((P.H % 32) == 0 && t512 >= 512) return launch_rs_cfg<8>(P, s);
+  const bool tall = (P.H % 32) == 0 && t512 >= 512;
+  // BatchNorm-backward sums of the destination, if the API layer asked for them and this launch can give them
+  const BnbFuse& f = g_bnb_fuse;
+  if (f.y != nullptr && f.tiles_out != nullptr && P.a0 == nullptr && P.dst1 == nullptr && P.stats == nullptr) {
+    const int64_t tiles = (int64_t)P.B * (P.H / (tall ? 32 : 16)) * (P.W / 16);
+    if (tiles * P.N * 2 <= f.max_elems) {
+      P.bnb_y = (const bf16_t*)f.y; P.bnb_a = f.a; P.bnb_b = f.b; P.bnb_mean = f.mean; P.bnb_invstd = f.invstd;
+      P.bnb_part = f.part;
+      *f.tiles_out = (int)tiles;
+    }
+  }
+  if (tall) return launch_rs_cfg<8>(P, s);
   return launch_rs_cfg<4>(P, s);
 }
 

@@ -10,6 +10,7 @@ namespace fu {
 
 thread_local const SyncDesc* g_sync = nullptr;
 thread_local const float* g_grad_unscale = nullptr;
+thread_local BnbFuse g_bnb_fuse;
 
 int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s) {
   const SyncDesc* d = g_sync;
@@ -591,9 +592,12 @@ static void launch_bn_bwd_pool_t(bool apply, int nb, size_t sh, hipStream_t s, v
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s, const void* g_pool, int B, int H, int W) {
+                  hipStream_t s, const void* g_pool, int B, int H, int W, int ext_partials) {
   (void)gamma;
   FU_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: channels must be a multiple of 4 and <= 1024 (got %d)", C);
+  // ext_partials > 0: `partials` already holds that many [C][2] rows of the two sums (written by the producer of g, see
+  // BnbFuse in fu_common.h) -- the reduce pass is skipped, the apply pass keeps its own grid
+  FU_REQUIRE(ext_partials == 0 || (g_pool == nullptr && sync_world() <= 1), "bn_bwd: external partial sums with a pooled source / exact sync");
   const int nb = bn_bwd_blocks(C, npix);
   const int rows = BNB_THREADS / (C >> 2);
   const size_t sh1 = (size_t)rows * C * 2 * sizeof(float);
@@ -603,6 +607,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     if (p == PREC_F32) launch_bn_bwd_pool_t<float>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else launch_bn_bwd_pool_t<f16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
+  } else if (ext_partials > 0) {
+    // (nothing to launch)
   } else if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const float*)g, (const float*)y,
                        C, npix, a, b, mean, invstd, partials);
@@ -615,7 +621,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   FU_LAUNCH_CHECK();
   if (sync_world() <= 1) {
     BnBwdOut o{g_grad_unscale, dgamma, dbeta, coef};
-    hipLaunchKernelGGL((k_bn_stats_fused<1, BnBwdOut>), dim3(C / 4), dim3(256), 0, s, partials, nb, C, (double)npix, o);
+    hipLaunchKernelGGL((k_bn_stats_fused<1, BnBwdOut>), dim3(C / 4), dim3(256), 0, s, partials,
+                       ext_partials > 0 ? ext_partials : nb, C, (double)npix, o);
     FU_LAUNCH_CHECK();
   } else {
     int G = 0;
@@ -1613,11 +1620,15 @@ int launch_dlogits_from_nchw(const float* dlogits_nchw, float* dlogits_nhwc, int
 // ------------------------------------------------------------------------------------------------
 static constexpr int HB_BLOCKS = 2048;
 
-template <typename T, int NC, int U>
+// BNB: also emit the BatchNorm-backward sums of g (sum g*m, sum g*m*xhat per channel, BnbFuse in fu_common.h) -- y and the
+// mask are in registers here anyway; bnpart[block][C][2], one row per block.
+template <typename T, int NC, int U, bool BNB>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y,
                                                   const float* __restrict__ a, const float* __restrict__ b,
                                                   const float* __restrict__ w, int C, int ncls_rt, int npix, int LPP,
-                                                  T* __restrict__ g, float* __restrict__ partials) {
+                                                  T* __restrict__ g, float* __restrict__ partials,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  float* __restrict__ bnpart) {
   constexpr int V = VecIO<T>::V;
   constexpr int KMAX = NC ? NC : HEAD_MAX_CLS;
   const int ncls = NC ? NC : ncls_rt;
@@ -1636,17 +1647,34 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, 
     for (int j = 0; j < V; ++j) { wv[k][j] = (k < ncls) ? w[k * C + lane_in * V + j] : 0.f; dw[k][j] = 0.f; }
     db[k] = 0.f;
   }
+  float iv[V], mi[V], s1[V], s2[V];                   // BNB: invstd, -mean * invstd, the two sums
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    iv[j] = BNB ? invstd[lane_in * V + j] : 0.f;
+    mi[j] = BNB ? -mean[lane_in * V + j] * iv[j] : 0.f;
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
   // U pixels per thread in flight per iteration; dW / db are summed per thread in visiting order, then per block in
   // LDS and over the blocks in k_head_bwd_finalize (fixed order, deterministic)
   for (int p0 = blockIdx.x * ppb * U; p0 < npix; p0 += gridDim.x * ppb * U) {
-    float z[U][V], d[U][KMAX];
+    float z[U][V], xh[BNB ? U : 1][V], d[U][KMAX];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = p0 + u * ppb + grp;
       const bool ok = p < npix;
 #pragma unroll
       for (int j = 0; j < V; ++j) z[u][j] = 0.f;
-      if (ok) load_act<T, V>(y + (size_t)p * C + lane_in * V, av, bv, bn, z[u]);
+      if constexpr (BNB) {
+        // (z = 0 marks the masked elements: the mask of the BatchNorm backward is a*y + b > 0, and z = max(a*y + b, 0))
+#pragma unroll
+        for (int j = 0; j < V; ++j) xh[u][j] = 0.f;
+        if (ok) {
+          float yv[V];
+          VecIO<T>::load(y + (size_t)p * C + lane_in * V, yv);
+#pragma unroll
+          for (int j = 0; j < V; ++j) { z[u][j] = bn_act(av[j], yv[j], bv[j]); xh[u][j] = fmaf(yv[j], iv[j], mi[j]); }
+        }
+      } else if (ok) load_act<T, V>(y + (size_t)p * C + lane_in * V, av, bv, bn, z[u]);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) d[u][k] = (ok && k < ncls) ? dl[(size_t)p * ncls + k] : 0.f;
     }
@@ -1666,6 +1694,14 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, 
           }
         }
         VecIO<T>::store(g + (size_t)p * C + lane_in * V, o);
+        if constexpr (BNB) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float gm = z[u][j] > 0.f ? o[j] : 0.f;
+            s1[j] += gm;
+            s2[j] = fmaf(gm, xh[u][j], s2[j]);
+          }
+        }
       }
     }
   }
@@ -1682,6 +1718,20 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, 
     float t = 0.f;
     for (int gq = 0; gq < ppb; ++gq) t += sm[gq * stride + e];
     partials[(size_t)blockIdx.x * stride + e] = t;
+  }
+  if constexpr (BNB) {
+    __syncthreads();                                   // sm: now [groups][C][2]
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      sm[(grp * C + lane_in * V + j) * 2 + 0] = s1[j];
+      sm[(grp * C + lane_in * V + j) * 2 + 1] = s2[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
+      float t = 0.f;
+      for (int gq = 0; gq < ppb; ++gq) t += sm[gq * 2 * C + e];
+      bnpart[(size_t)blockIdx.x * 2 * C + e] = t;
+    }
   }
 }
 
@@ -1707,7 +1757,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_finalize(const float* __restri
 int64_t head_bwd_partial_elems(int C, int ncls) { return (int64_t)HB_BLOCKS * (ncls * C + ncls); }
 
 int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const float* a, const float* b, const float* w,
-                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s) {
+                    int C, int ncls, int64_t npix, void* g, float* partials, float* dw, float* db, hipStream_t s,
+                    const BnbFuse* fuse) {
   FU_REQUIRE(npix < ((int64_t)1 << 31), "head_bwd: too many pixels");
   int LPP;
   if (p == PREC_F32) FU_REQUIRE(head_geometry<float>(C, &LPP), "head_bwd: unsupported channel count %d", C);
@@ -1718,11 +1769,24 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
   int nblk = (int)ceil_div64(npix, (int64_t)ppb * U);
   if (nblk > HB_BLOCKS) nblk = HB_BLOCKS;
   const int stride = ncls * C + ncls;
-  const size_t sh = (size_t)ppb * stride * sizeof(float);
+  // the BatchNorm-backward sums of g, if asked for (16-bit modes with BatchNorm coefficients: the bench path)
+  const bool bnb = fuse && fuse->y == y && fuse->tiles_out && a != nullptr && p != PREC_F32 &&
+                   (int64_t)nblk * C * 2 <= fuse->max_elems;
+  size_t sh = (size_t)ppb * stride * sizeof(float);
+  if (bnb && (size_t)ppb * C * 2 * sizeof(float) > sh) sh = (size_t)ppb * C * 2 * sizeof(float);
   FU_REQUIRE(sh <= 64 * 1024, "head_bwd: LDS request too large (%zu)", sh);
+  const float* bmean = bnb ? fuse->mean : nullptr;
+  const float* binv = bnb ? fuse->invstd : nullptr;
+  float* bpart = bnb ? fuse->part : nullptr;
 #define FU_HEAD_BWD(TT, NC)                                                                                     \
-  hipLaunchKernelGGL((k_head_bwd<TT, NC, U>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, w, C, ncls, \
-                     (int)npix, LPP, (TT*)g, partials)
+  do {                                                                                                          \
+    if (bnb)                                                                                                    \
+      hipLaunchKernelGGL((k_head_bwd<TT, NC, U, true>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, w, C, \
+                         ncls, (int)npix, LPP, (TT*)g, partials, bmean, binv, bpart);                           \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_head_bwd<TT, NC, U, false>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, w, \
+                         C, ncls, (int)npix, LPP, (TT*)g, partials, bmean, binv, bpart);                         \
+  } while (0)
   if (p == PREC_F32) {
     switch (ncls) {
       case 1: FU_HEAD_BWD(float, 1); break;
@@ -1753,6 +1817,7 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
   hipLaunchKernelGGL(k_head_bwd_finalize, dim3(ceil_div(stride, 8)), dim3(256), 0, s, partials, nblk, C, ncls,
                      g_grad_unscale, dw, db);
   FU_LAUNCH_CHECK();
+  if (bnb) *fuse->tiles_out = nblk;
   return 0;
 }
 

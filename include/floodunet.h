@@ -250,6 +250,10 @@ void fu_test_force_lockstep_wgrad(int on);
  * 1 = never the tall 16x32-pixel tile (nor the row-stationary kernel), 2 = the tall tile wherever 64-channel tiles run,
  * 3 = the row-stationary kernel (fu_conv_rs.hip) wherever the shape is eligible.  Process-wide. */
 void fu_test_conv_tile_mode(int mode);
+/* Testing hook: on != 0 computes every BatchNorm-backward pair of sums with its own reduce pass; by default the 16-bit
+ * modes take them from the kernel that produces the gradient where it can (row-stationary dgrad, head backward).
+ * Process-wide. */
+void fu_test_bnb_separate(int on);
 /* Testing hook: on != 0 runs the late-fusion 1x1 convs (weights embedded as the centre tap of a 3x3) through all nine taps
  * instead of the 1-tap instantiation of the fast kernel; the other eight taps multiply exact zeros, so the results are
  * bit-identical.  Process-wide. */

@@ -335,6 +335,32 @@ def test_full_size_properties(prec):
         finally:
             lib.fu_test_force_lockstep_wgrad(0)
             _lib.check(lib.fu_set_side_stream(net._ctx, 1))
+        # BatchNorm-backward sums from the producer of the gradient (row-stationary dgrad epilogue, head backward) against
+        # the separate reduce pass.  The head's sums differ only in summation order and in using g before its rounding
+        # (dgamma / dbeta of the last BatchNorm: 1e-4); one layer further the changed coefficients have re-rounded dy
+        # (measured decorrelation as above), a wrong sum would be off by O(1) there and in everything upstream.
+        try:
+            lib.fu_test_bnb_separate(1)
+            l5 = net.train_step(x, t, 0).item()
+            g5 = net.flat_grads().clone()
+            torch.cuda.synchronize()
+        finally:
+            lib.fu_test_bnb_separate(0)
+        assert l5 == l1
+        tight = {"up4.conv.double_conv.4.weight": 1e-4, "up4.conv.double_conv.4.bias": 1e-4,
+                 "up4.conv.double_conv.1.weight": 0.03, "up4.conv.double_conv.1.bias": 0.03,
+                 "outc.conv.weight": 0.0, "outc.conv.bias": 0.0, "up4.conv.double_conv.3.weight": 1e-3}
+        seen = 0
+        for (k, p), gv1, gv5 in zip(net.named_parameters(), _views(net, g1), _views(net, g5)):
+            if is_dead_bias(k) or gv1.norm().item() < 1e-7:
+                continue
+            if k in tight:
+                seen += 1
+                assert rel(gv5, gv1) <= tight[k], (k, rel(gv5, gv1))
+            elif p.dim() == 4:
+                assert rel(gv5, gv1) <= 0.35, (k, rel(gv5, gv1))
+        assert seen == len(tight)
+        assert not torch.equal(g5, g1)          # the two routes are really different code
     net.eval()
     with torch.no_grad():
         full = net(x)
