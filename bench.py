@@ -417,6 +417,7 @@ def main():
     # event-timed durations in the timed region include that sharing.  A short extra pass with the side stream off
     # (fu_set_side_stream) gives the same kernel's un-shared rate as `achieved_serial` (not part of `value`).
     serial = None
+    serial_conv_only = None
     if best and world == 1 and not args.no_serial_pass and args.path == "cabi":
         _lib.check(lib.fu_set_side_stream(net._ctx, 0))
         trainer.step(x, target, 0)
@@ -430,6 +431,23 @@ def main():
         _lib.check(lib.fu_profile_read(net._ctx, cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(name)))
         if n.value:
             serial = fl.value / (ms.value * 1e-3) / 1e12
+        # In the 16-bit modes 9 of the 35 conv launches of a step (the dgrads into a block's first BatchNorm) also compute
+        # that BatchNorm's backward sums in their epilogue -- non-conv work inside the dominant kernel's
+        # time.  Same pass once more with those sums back in their own kernel: the conv kernels' rate for conv work only.
+        if args.dtype != "f32" and cls == 0:
+            lib.fu_test_bnb_separate(1)
+            try:
+                trainer.step(x, target, 0)
+                _lib.check(lib.fu_profile_enable(net._ctx, 1))
+                for _ in range(3):
+                    trainer.step(x, target, 0)
+                torch.cuda.synchronize(dev)
+                _lib.check(lib.fu_profile_enable(net._ctx, 0))
+                _lib.check(lib.fu_profile_read(net._ctx, cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(name)))
+                if n.value:
+                    serial_conv_only = fl.value / (ms.value * 1e-3) / 1e12
+            finally:
+                lib.fu_test_bnb_separate(0)
         _lib.check(lib.fu_set_side_stream(net._ctx, 1))
     if best:
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
@@ -442,6 +460,12 @@ def main():
         if serial is not None:
             roof["achieved_serial"] = round(serial, 3)
             roof["frac_serial"] = round(serial / peak, 4)
+        if serial_conv_only is not None:
+            roof["achieved_serial_conv_only"] = round(serial_conv_only, 3)
+            roof["frac_serial_conv_only"] = round(serial_conv_only / peak, 4)
+            roof["fused_work"] = ("9 of the 35 launches per step (dgrad into a block's first BatchNorm) also emit that "
+                                  "BatchNorm's backward sums from their epilogue; *_conv_only = the same pass with those sums "
+                                  "in their own kernel (fu_test_bnb_separate)")
         if traffic:   # HBM bytes per launch (PMC passes) over the live launch duration, against the 8 TB/s HBM3E peak
             gbps = traffic / (best["ms"] / best["launches"] * 1e-3) / 1e9
             roof["hbm_gbps"] = round(gbps, 1)

@@ -322,6 +322,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   const unsigned long long m1 = __builtin_amdgcn_s_memtime();
   if (nChunks == 1) T1 = m1;
 #endif
+  // BatchNorm-backward sums (BnbFuse): the y rows of the tile.  The first NPRE of them are requested here -- the last
+  // block issues no activation loads, so they ride in the registers those would occupy and have landed when the block
+  // ends -- the rest at the start of the epilogue.
+  constexpr int NPRE = A_ITERS / 2;
+  uint4 yr[Cfg::ROWS][2];
+  const char* ybase = nullptr;
+  if (bnb) {
+    ybase = reinterpret_cast<const char*>(P.bnb_y) +
+            ((size_t)((bb * P.H + y0 + wm * Cfg::ROWS) * P.W + x0 + lx) * (size_t)P.N + (size_t)(n0 + 16 * lg)) * 2;
+#pragma unroll
+    for (int ro = 0; ro < NPRE; ++ro) {
+      const char* yp = ybase + (size_t)ro * (size_t)(P.W * P.N) * 2;
+      yr[ro][0] = *reinterpret_cast<const uint4*>(yp);
+      yr[ro][1] = *reinterpret_cast<const uint4*>(yp + 16);
+    }
+  }
   mfma_block(std::false_type{});
 #ifdef FU_CONV_STAMPS
   const unsigned long long T2 = __builtin_amdgcn_s_memtime();
@@ -366,45 +382,62 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   };
   if (bnb) {
     // BatchNorm-backward sums of the destination (BnbFuse, fu_common.h): g = the accumulators (fp32, before their rounding
-    // to the element type), y = the BatchNorm's raw input at the same pixels and channels.  Channel-group major: the four
+    // to the element type), y = the BatchNorm's raw input at the same pixels and channels.  Channel-group major: the
     // coefficients of four channels stay in registers while the rows stream past, all y rows are resident (2 x 16 bytes
-    // per row and lane) -- row major would keep 64 coefficient registers live beside the 128 accumulators.
-    uint4 yr[Cfg::ROWS][2];
+    // per row and lane) -- row major would keep 32 coefficient registers live beside the 128 accumulators.  Six VALU
+    // instructions per element: the second sum is accumulated against the raw y and turned into sum g*m*xhat =
+    // invstd * (sum g*m*y - mean * sum g*m) once per tile and channel (fp32; the 16-bit modes only).
 #pragma unroll
-    for (int ro = 0; ro < Cfg::ROWS; ++ro) {
-      const int oy = y0 + wm * Cfg::ROWS + ro, ox = x0 + lx;
-      const char* yp = reinterpret_cast<const char*>(P.bnb_y) +
-                       ((size_t)((bb * P.H + oy) * P.W + ox) * (size_t)P.N + (size_t)(n0 + 16 * lg)) * 2;
+    for (int ro = NPRE; ro < Cfg::ROWS; ++ro) {
+      const char* yp = ybase + (size_t)ro * (size_t)(P.W * P.N) * 2;
       yr[ro][0] = *reinterpret_cast<const uint4*>(yp);
       yr[ro][1] = *reinterpret_cast<const uint4*>(yp + 16);
     }
-    float u[16], q[16];
+    auto row_sum = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+      return v;
+    };
+    float* red = reinterpret_cast<float*>(smem_raw);            // [4 waves][64 channels][2]: the activation tile is done
+    __syncthreads();                                            // ... once every wave has left the last block
     static_for<0, 4>([&](auto Sc) {
       constexpr int s = decltype(Sc)::value;
       const float4 ca = *reinterpret_cast<const float4*>(sAB + 16 * lg + 4 * s);
       const float4 cb = *reinterpret_cast<const float4*>(sAB + 64 + 16 * lg + 4 * s);
-      const float4 ci = *reinterpret_cast<const float4*>(sAB + 128 + 16 * lg + 4 * s);
-      const float4 cm = *reinterpret_cast<const float4*>(sAB + 192 + 16 * lg + 4 * s);
+      const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w};
       float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ro = 0; ro < Cfg::ROWS; ++ro) {
         const uint4 w4 = yr[ro][s >> 1];
         const unsigned w01 = (s & 1) ? w4.z : w4.x, w23 = (s & 1) ? w4.w : w4.y;    // channels 4s, 4s+1 | 4s+2, 4s+3
         const float yv[4] = {e2f_lo(w01), e2f_hi(w01), e2f_lo(w23), e2f_hi(w23)};
-        const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w};
-        const float iv[4] = {ci.x, ci.y, ci.z, ci.w}, mv[4] = {cm.x, cm.y, cm.z, cm.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float gm = fmaf(av[k], yv[k], bv[k]) > 0.f ? acc[ro][s][k] : 0.f;
           t1[k] += gm;
-          t2[k] = fmaf(gm, fmaf(yv[k], iv[k], mv[k]), t2[k]);
+          t2[k] = fmaf(gm, yv[k], t2[k]);
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { u[4 * s + k] = t1[k]; q[4 * s + k] = t2[k]; }
+      for (int k = 0; k < 4; ++k) {
+        const float r1 = row_sum(t1[k]), r2 = row_sum(t2[k]);
+        if (lx == 15) {
+          red[(wm * BN + 16 * lg + 4 * s + k) * 2 + 0] = r1;
+          red[(wm * BN + 16 * lg + 4 * s + k) * 2 + 1] = r2;
+        }
+      }
     });
-    tile_sums_out(u, q, P.bnb_part);
-    __syncthreads();                                  // `red` aliases the tile; nothing below reads LDS but sAB
+    __syncthreads();
+    if (tid < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { s1 += red[(m * BN + tid) * 2 + 0]; s2 += red[(m * BN + tid) * 2 + 1]; }
+      float* o = P.bnb_part + ((int64_t)pixT * P.N + n0 + tid) * 2;
+      o[0] = s1;
+      o[1] = fmaf(sAB[128 + tid], s2, sAB[192 + tid] * s1);      // invstd * s2 - mean * invstd * s1
+    }
   }
   float ssum[16], ssq[16], biasv[16];
 #pragma unroll
