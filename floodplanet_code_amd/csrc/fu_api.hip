@@ -306,7 +306,11 @@ struct fu_ctx {
   int64_t bnb_cap = 0;         // floats
   float* db_part = nullptr;
   float* db_part2 = nullptr;      // second bias-gradient partial buffer (side-stream wgrad, alternating per conv)
-  hipStream_t side = nullptr;     // side stream for the weight-gradient chain (wgrad + slab reduce + transpose)
+  hipStream_t side = nullptr;     // side stream for the weight-gradient chain (wgrad + slab reduce + transpose): one of ...
+  hipStream_t side_lo = nullptr;  // ... lowest priority (mode 1: nothing but the final join waits for that chain; the main chain
+                                  //     conv -> BN backward -> conv is the critical path and gets the CUs first: measured
+                                  //     5.66 -> 5.64 ms per step and 0.338 -> 0.350 of peak for the conv launches in the step)
+  hipStream_t side_def = nullptr; // ... the default priority (mode 2: an all-reduce bucket waits for its weight gradients)
   hipEvent_t ev_gy = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_blk = nullptr;
   int wg_parity = 0;
   int side_mode = 1;              // fu_set_side_stream: 0 off, 1 on (blocks join), 2 on (the caller joins: fu_backward_join)
@@ -1017,13 +1021,23 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   // (bf16 only: in fp32 mode the concurrency changes nothing in the step time -- both kernels are MFMA bound at 0.7 of
   //  the fp32 peak -- and only inflates the per-launch durations of the parity build)
   if (st == 0 && c->cfg.bilinear && c->prec != fu::PREC_F32 && !getenv("FU_NO_SIDE_STREAM")) {
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+    int plo = 0, phi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // plo = the lowest priority (numerically largest)
+    if (hipStreamCreateWithFlags(&c->side_def, hipStreamNonBlocking) != hipSuccess) c->side_def = nullptr;
+    if (c->side_def && !getenv("FU_SIDE_PRIO_DEFAULT") &&
+        hipStreamCreateWithPriority(&c->side_lo, hipStreamNonBlocking, plo) != hipSuccess)
+      c->side_lo = nullptr;
+    c->side = c->side_lo ? c->side_lo : c->side_def;        // side_mode starts at 1
     if (c->side) {
       bool ok = hipEventCreateWithFlags(&c->ev_gy, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&c->ev_wg[0], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&c->ev_wg[1], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&c->ev_blk, hipEventDisableTiming) == hipSuccess;
-      if (!ok) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+      if (!ok) {
+        if (c->side_lo) (void)hipStreamDestroy(c->side_lo);
+        (void)hipStreamDestroy(c->side_def);
+        c->side = c->side_lo = c->side_def = nullptr;
+      }
     }
   }
   if (st != 0) { fu_destroy(c); return st; }
@@ -1037,7 +1051,8 @@ int fu_destroy(fu_ctx* c) {
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
   if (c->side) {
-    (void)hipStreamDestroy(c->side);
+    if (c->side_lo) (void)hipStreamDestroy(c->side_lo);
+    if (c->side_def) (void)hipStreamDestroy(c->side_def);
     for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk}) if (e) (void)hipEventDestroy(e);
   }
   if (c->arena.base) (void)hipFree(c->arena.base);
@@ -1180,6 +1195,7 @@ int fu_backward_block(fu_ctx* c, int block, const float* dlogits, fu_stream stre
 int fu_set_side_stream(fu_ctx* c, int mode) {
   FU_REQUIRE(c && mode >= 0 && mode <= 2, "fu_set_side_stream: mode must be 0, 1 or 2");
   c->side_mode = mode;
+  if (c->side) c->side = (mode == 2 || !c->side_lo) ? c->side_def : c->side_lo;
   return FU_OK;
 }
 
