@@ -857,18 +857,27 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gds
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
   const T* base = gdst + (size_t)bb * outH * outW * C + cv * V;
+  // the column list of this lane once, ahead of the row loop (it was re-read from the table inside it, a dependent load
+  // and a data-dependent break per tap); same taps in the same order, so the sums are unchanged
+  int xo[UP_BWD_MAX];
+  float xw[UP_BWD_MAX];
+#pragma unroll
+  for (int jx = 0; jx < UP_BWD_MAX; ++jx) { xo[jx] = t.xb_o[ix * UP_BWD_MAX + jx]; xw[jx] = t.xb_w[ix * UP_BWD_MAX + jx]; }
   for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
     const int oy = t.yb_o[iy * UP_BWD_MAX + jy];                // block-uniform
     if (oy < 0) break;
     const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
-    for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
-      const int ox = t.xb_o[ix * UP_BWD_MAX + jx];
-      if (ox < 0) break;
-      const float w = wy * t.xb_w[ix * UP_BWD_MAX + jx];
-      float gv[V];
-      VecIO<T>::load(base + ((size_t)(oy + py0) * outW + (ox + px0)) * C, gv);
+    const T* rowp = base + (size_t)(oy + py0) * outW * C;
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc[j] += w * gv[j];
+    for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
+      if (__builtin_amdgcn_ballot_w64(xo[jx] >= 0) == 0) break;  // wave-uniform: lists are filled front to back
+      if (xo[jx] >= 0) {
+        const float w = wy * xw[jx];
+        float gv[V];
+        VecIO<T>::load(rowp + (size_t)(xo[jx] + px0) * C, gv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += w * gv[j];
+      }
     }
   }
   VecIO<T>::store(gsrc + ((size_t)(bb * H + iy) * W + ix) * C + cv * V, acc);
