@@ -201,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
   const unsigned long long R0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz: cycles / ticks = the clock the chip holds
   unsigned long long T0 = __builtin_amdgcn_s_memtime(), T1 = 0, Sbar = 0, Sstore = 0, Swait = 0, Smfma = 0, Sload = 0, Sdma = 0;
 #endif
-  load_begin(0);
-  static_for<0, A_ITERS>([&](auto Sc) { load_slot(Sc); });
-  dma_weights(0);                                   // LDS is free at kernel start
+  // Coefficient tables first: their loads are waited for (vmcnt counts in order) before the LDS writes below, and issued
+  // behind the activation loads and the weight DMA that wait would cover those too -- the first stage could then not start
+  // converting while the DMA is still in flight.
   if (tid < BN) sAB[1024 + tid] = P.bias != nullptr ? P.bias[n0 + tid] : 0.f;     // (16 registers per lane if kept live)
   if (has_bn) {
     for (int c = tid; c < P.C0; c += NT) { sAB[c] = P.a0[c]; sAB[512 + c] = P.b0[c]; }
@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
     const float iv = P.bnb_invstd[c];
     sAB[tid] = P.bnb_a[c]; sAB[64 + tid] = P.bnb_b[c]; sAB[128 + tid] = iv; sAB[192 + tid] = -P.bnb_mean[c] * iv;
   }
+  load_begin(0);
+  static_for<0, A_ITERS>([&](auto Sc) { load_slot(Sc); });
+  dma_weights(0);                                   // LDS is free at kernel start
 
   // One chunk: for each column shift dx and subtile pair sp, the six weight fragments (3 kernel rows x 2 subtiles) stay
   // in registers while the ten input rows stream past; input row ri feeds output rows ri - dy.
