@@ -1,5 +1,5 @@
-import csv,glob,sys
-f=glob.glob(sys.argv[1]+'/*/*_kernel_trace.csv')[0]
+import csv,glob,os,sys
+f=max(glob.glob(sys.argv[1]+'/*/*_kernel_trace.csv'), key=os.path.getmtime)   # gpurun_out/ accumulates runs: the newest one
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 idx=[i for i,r in enumerate(rows) if 'k_nchw_to_nhwc' in r['Kernel_Name']]
