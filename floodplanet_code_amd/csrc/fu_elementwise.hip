@@ -73,6 +73,24 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ src, T* __restrict__ ds
   }
 }
 
+// 16-bit destinations with c_pad % 8 == 0 (the training path): one thread per (pixel, channel octet) -- eight plane reads
+// that are coalesced across the threads of a wave, one 16-byte store; 32-bit indices.  (The flat kernel above decodes a
+// 64-bit index twice per ELEMENT and reads with a stride of H*W floats between neighbouring threads.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_v8(const float* __restrict__ src, T* __restrict__ dst, int C, int HW,
+                                                          int cpad, int srcC) {
+  const int p = blockIdx.x * 256 + threadIdx.x;        // pixel inside the sample
+  const int o = blockIdx.y, b = blockIdx.z;            // channel octet, sample
+  if (p >= HW) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j;
+    v[j] = c < C ? src[((size_t)b * srcC + c) * HW + p] : 0.f;
+  }
+  VecIO<T>::store(dst + ((size_t)b * HW + p) * cpad + o * 8, v);
+}
+
 template <typename T>
 __global__ void k_nhwc_to_nchw(const T* __restrict__ src, float* __restrict__ dst, int C, int HW, int cpad,
                                int64_t total) {
@@ -93,6 +111,15 @@ int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H
   const int g = grid_for(total, 256);
   const int srcC = src_channels > 0 ? src_channels : C;
   src += (int64_t)src_channel_offset * H * W;
+  if (p != PREC_F32 && c_pad % 8 == 0 && B <= 65535 && c_pad / 8 <= 65535) {
+    const dim3 g8((unsigned)ceil_div(H * W, 256), (unsigned)(c_pad / 8), (unsigned)B);
+    if (p == PREC_BF16)
+      hipLaunchKernelGGL(k_nchw_to_nhwc_v8<bf16_t>, g8, dim3(256), 0, s, src, (bf16_t*)dst, C, H * W, c_pad, srcC);
+    else
+      hipLaunchKernelGGL(k_nchw_to_nhwc_v8<f16_t>, g8, dim3(256), 0, s, src, (f16_t*)dst, C, H * W, c_pad, srcC);
+    FU_LAUNCH_CHECK();
+    return 0;
+  }
   if (p == PREC_F32)
     hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, C, H * W, c_pad, total, srcC);
   else if (p == PREC_BF16)
