@@ -508,8 +508,8 @@ __global__ void k_bn_bwd_pool(T* __restrict__ g, const T* __restrict__ y, const 
   const int rows = BNB_THREADS / CV;
   const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
   const int Ho = H >> 1, Wo = W >> 1, Hw = (H + 1) >> 1, Ww = (W + 1) >> 1;     // pool outputs; windows incl. odd edges
-  const int nwin = B * Hw * Ww;             // < 2^31 and every tensor < 2^31 elements (launch_bn_bwd checks): 32-bit indices,
-                                            // window decode by host reciprocals (it was two 64-bit divisions per window)
+  const int nwin = B * Hw * Ww;             // pixel and window counts < 2^31 (launch_bn_bwd checks): 32-bit window decode by
+                                            // host reciprocals (it was two 64-bit divisions per window); 64-bit element offsets
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (row < rows) {
     float av[4], bv[4], mv[4], iv[4], c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
@@ -529,18 +529,18 @@ __global__ void k_bn_bwd_pool(T* __restrict__ g, const T* __restrict__ y, const 
       const bool pooled = wy < Ho && wx < Wo;                     // complete window: has a pool output
       float yv[4][4], gv[4][4], z[4][4], gp[4] = {0, 0, 0, 0};
       bool ok[4];
-      int off[4];
+      int64_t off[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int py = 2 * wy + (q >> 1), px = 2 * wx + (q & 1);
         ok[q] = py < H && px < W;
-        off[q] = (((bb * H + (ok[q] ? py : 0)) * W + (ok[q] ? px : 0)) * C) + cv * 4;
+        off[q] = (int64_t)((bb * H + (ok[q] ? py : 0)) * W + (ok[q] ? px : 0)) * C + cv * 4;
         ElemIO<T>::load4(y + off[q], yv[q]);
         ElemIO<T>::load4(g + off[q], gv[q]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[q][j] = bn_act_pre(av[j], yv[q][j], bv[j]);
       }
-      if (pooled) ElemIO<T>::load4(gpool + (((bb * Ho + wy) * Wo + wx) * C) + cv * 4, gp);
+      if (pooled) ElemIO<T>::load4(gpool + (int64_t)((bb * Ho + wy) * Wo + wx) * C + cv * 4, gp);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int am = 0;
@@ -634,8 +634,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   const bool pool = g_pool != nullptr;     // the max-pool backward of this tensor is folded into the two passes
   if (pool) {
     FU_REQUIRE((int64_t)B * H * W == npix && BNB_THREADS % (C >> 2) == 0, "bn_bwd (pooled): bad geometry");
-    FU_REQUIRE(npix * C < ((int64_t)1 << 31) && (int64_t)B * ((H + 1) / 2) * (int64_t)((W + 1) / 2) * ((W + 1) / 2) < ((int64_t)1 << 32),
-               "bn_bwd (pooled): tensor too large for 32-bit indices");
+    FU_REQUIRE(npix < ((int64_t)1 << 31) && (int64_t)B * ((H + 1) / 2) * (int64_t)((W + 1) / 2) * ((W + 1) / 2) < ((int64_t)1 << 32),
+               "bn_bwd (pooled): more than 2^31 pixels");
     if (p == PREC_F32) launch_bn_bwd_pool_t<float>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else launch_bn_bwd_pool_t<f16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
