@@ -89,6 +89,8 @@ SIGNATURES = {
     "fu_test_conv_tile_mode": (None, [_i]),
     "fu_test_bnb_separate": (None, [_i]),
     "fu_test_force_full_taps": (None, [_i]),
+    "fu_test_perturb_bnb_sums": (None, [_f]),
+    "fu_test_get_buffer": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i64)]),
     "fu_set_side_stream": (_i, [_p, _i]),
     "fu_backward_join": (_i, [_p, _p]),
     "fu_set_exact_sync": (_i, [_p, SYNC_HOOK, _p, _i, _p, _i64]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     "fu_op_conv3x3_fwd": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "fu_op_conv3x3_dgrad": (_i, [_i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "fu_op_conv3x3_wgrad": (_i, [_i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "fu_op_conv3x3_dgrad_bnsums": (_i, [_i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fu_op_head_bwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "fu_op_bn_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "fu_op_maxpool2": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fu_op_upsample2": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
 }

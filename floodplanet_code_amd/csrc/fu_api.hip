@@ -300,7 +300,10 @@ struct fu_ctx {
   Arena arena;
   std::vector<void*> extra_allocs;
   float* logits = nullptr;
-  float* dlogits = nullptr;
+  float* dlogits = nullptr;        // dL/dlogits as fu_loss_* (or the caller) left it: never modified by a backward
+  float* dlogits_eff = nullptr;    // times the upstream gradient / the fp16 loss scale (launch_loss_grad_eff)
+  float* up_scale = nullptr;       // device scalar: upstream gradient of the loss (fu_scale_loss_grad)
+  bool have_up_scale = false;
   float* stats = nullptr;
   float* bnb_part = nullptr;
   int64_t bnb_cap = 0;         // floats
@@ -321,7 +324,7 @@ struct fu_ctx {
   float* ce_part = nullptr;
   float* hb_part = nullptr;
   float* loss_dev = nullptr;
-  float* loss_scale = nullptr;    // fp16 mode: {S, 1/S} of the running backward (fu_common.h, launch_loss_scale)
+  float* loss_scale = nullptr;    // fp16 mode: {S, 1/S} of the running backward (fu_common.h, launch_loss_grad_eff)
   unsigned long long* conf_tmp = nullptr;
   int64_t* n_valid = nullptr;
   float* adam_m = nullptr;        // bound (caller-owned, fu_bind_adam_state): the moments outlive the context
@@ -558,6 +561,8 @@ int alloc_workspace(fu_ctx* c) {
   const int64_t npix0 = (int64_t)B * f.height * f.width;
   A.want(&c->logits, npix0 * f.n_classes * sizeof(float));
   A.want(&c->dlogits, npix0 * f.n_classes * sizeof(float));
+  A.want(&c->dlogits_eff, npix0 * f.n_classes * sizeof(float));
+  A.want(&c->up_scale, 256);
   A.want(&c->stats, max_stats * sizeof(float));
   A.want(&c->bnb_part, max_bnb * sizeof(float));
   c->bnb_cap = max_bnb;
@@ -788,12 +793,24 @@ int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_
   c->last_batch = B;
   c->fwd_training = training;
   c->have_loss = false;
+  c->have_up_scale = false;
   return 0;
 }
 
 // testing hook (fu_test_bnb_separate) and A/B switch (environment FU_BNB_SEPARATE): 1 = BatchNorm-backward sums always by
 // their own reduce pass, never from the producer of the gradient (BnbFuse, fu_common.h)
 static int g_bnb_separate = getenv("FU_BNB_SEPARATE") != nullptr ? 1 : 0;
+// testing hook (fu_test_perturb_bnb_sums): the fused sums are multiplied by this factor after the kernel that emitted
+// them -- the negative control of the parity tests (a wrong fused sum must make them fail); 1 = off, no launch
+static float g_test_perturb_bnb = 1.f;
+__global__ void k_scale_floats(float* x, int64_t n, float f) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= f;
+}
+int perturb_bnb(float* part, int tiles, int C, hipStream_t s) {
+  if (g_test_perturb_bnb == 1.f || tiles <= 0) return 0;
+  hipLaunchKernelGGL(k_scale_floats, dim3(256), dim3(256), 0, s, part, (int64_t)tiles * C * 2, g_test_perturb_bnb);
+  return hipGetLastError() == hipSuccess ? 0 : FU_ERR_HIP;
+}
 
 int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   Block& K = c->blk[i];
@@ -851,6 +868,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     g_bnb_fuse = BnbFuse();
     if (st) return st;
     v0.bnb_tiles = tiles;
+    FU_TRY(perturb_bnb(c->bnb_part, tiles, v0.cout, s));
   } else if (K.kind == BK_DOWN) {
     ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.g_pooled, v.cin_real, nullptr, 0, nullptr, nullptr, B, H, W,
@@ -903,12 +921,22 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
   const fu_config& f = c->cfg;
   const int B = c->last_batch;
   if (block == 0) {
-    if (dlogits_ext)
+    if (dlogits_ext) {
       FU_TRY(launch_dlogits_from_nchw(dlogits_ext, c->dlogits, f.n_classes, B, f.height, f.width, s));
-    else
+      c->have_up_scale = false;     // the caller's dlogits IS the whole upstream gradient
+    } else {
       FU_REQUIRE(c->have_loss, "fu_backward: no dlogits given and no fu_loss_* call since the last forward");
-    if (c->prec == PREC_F16)      // fp16 gradient maps: power-of-two loss scale from max|dL/dlogits| (UnscaleScope removes it)
-      FU_TRY(launch_loss_scale(c->dlogits, (int64_t)B * f.height * f.width * f.n_classes, c->ce_part, c->loss_scale, s));
+    }
+    // What the head backward reads: the stored gradient itself, or -- out of place, so that a repeated backward of the same
+    // loss starts from the same input -- times the upstream gradient of loss.backward() and, for fp16 gradient maps, the
+    // power-of-two loss scale chosen from max|dL/dlogits| (UnscaleScope removes it where parameter gradients are written)
+    const float* dl = c->dlogits;
+    if (c->prec == PREC_F16 || c->have_up_scale) {
+      FU_TRY(launch_loss_grad_eff(c->dlogits, c->dlogits_eff, (int64_t)B * f.height * f.width * f.n_classes,
+                                  c->have_up_scale ? c->up_scale : nullptr, c->ce_part,
+                                  c->prec == PREC_F16 ? c->loss_scale : nullptr, s));
+      dl = c->dlogits_eff;
+    }
     Conv& last = c->blk[c->nb - 1].c[1];
     // the head's data gradient is dL/d relu(bn(y)) of the last conv: it can leave that BatchNorm's backward sums behind
     BnbFuse fz;
@@ -918,10 +946,11 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
       fz.y = last.y; fz.a = last.a; fz.b = last.b; fz.mean = last.mean; fz.invstd = last.invstd;
       fz.part = c->bnb_part; fz.max_elems = c->bnb_cap; fz.tiles_out = &tiles;
     }
-    FU_TRY(launch_head_bwd(c->prec, c->dlogits, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
+    FU_TRY(launch_head_bwd(c->prec, dl, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
                            (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s,
                            want ? &fz : nullptr));
     last.bnb_tiles = tiles;
+    FU_TRY(perturb_bnb(c->bnb_part, tiles, last.cout, s));
     return 0;
   }
   if (c->fusion && block == 5) {
@@ -1149,6 +1178,7 @@ int fu_loss_ce(fu_ctx* c, const int64_t* target, int ignore_index, float* loss_o
   if (c->fwd_training) {
     FU_TRY(launch_ce_grad(c->logits, target, c->cfg.n_classes, ignore_index, npix, c->n_valid, c->dlogits, s));
     c->have_loss = true;
+    c->have_up_scale = false;
   }
   return FU_OK;
 }
@@ -1162,7 +1192,7 @@ int fu_loss_bce_dice(fu_ctx* c, const int64_t* target, int ignore_index, float d
   FU_TRY(launch_bce_dice(c->logits, target, c->cfg.n_classes, ignore_index, npix, dice_weight, c->ce_part,
                          c->loss_dev + 8, loss_out ? loss_out : c->loss_dev, c->n_valid,
                          c->fwd_training ? c->dlogits : nullptr, s));
-  if (c->fwd_training) c->have_loss = true;
+  if (c->fwd_training) { c->have_loss = true; c->have_up_scale = false; }
   return FU_OK;
 }
 
@@ -1172,8 +1202,11 @@ int fu_scale_loss_grad(fu_ctx* c, const float* scale_dev, fu_stream stream) {
     set_error("fu_scale_loss_grad: no loss gradient stored (training fu_forward + fu_loss_* first)");
     return FU_ERR_STATE;
   }
-  const int64_t n = (int64_t)c->last_batch * c->cfg.height * c->cfg.width * c->cfg.n_classes;
-  return launch_scale_by_device_scalar(c->dlogits, n, scale_dev, (hipStream_t)stream);
+  // kept as a device scalar and applied when the backward forms the head's input (backward_block_impl, block 0): the stored
+  // gradient is not touched, calling this twice for one loss replaces the factor instead of compounding it
+  FU_HIP_CHECK(hipMemcpyAsync(c->up_scale, scale_dev, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  c->have_up_scale = true;
+  return FU_OK;
 }
 
 int fu_num_blocks(const fu_ctx* c) { return c ? num_backward_blocks(c) : 0; }
@@ -1461,6 +1494,118 @@ int fu_op_upsample2(int precision, const void* src, const float* bn_a, const flo
   return st;
 }
 
+// ---- op-level test hooks for the code that only runs in the benched dispatch (fused BatchNorm-backward sums) ------------
+namespace {
+// [nTiles][C][2] partial rows -> per-channel sums, fp64 accumulation in tile order
+int collapse_partials(const float* part, int nTiles, int C, float* s1, float* s2, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats_collapse, dim3(ceil_div(C, 64)), dim3(64), 0, s, part, nTiles, C, s1, s2);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("collapse launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
+  return 0;
+}
+}  // namespace
+
+int fu_op_conv3x3_dgrad_bnsums(int precision, const void* dy, int Cout, const float* w_oihw, void* dx, int C0,
+                               const void* y, const float* bn_a, const float* bn_b, const float* mean,
+                               const float* invstd, float* sum_gm, float* sum_gmx, int B, int H, int W,
+                               fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  FU_REQUIRE(p != PREC_F32, "fu_op_conv3x3_dgrad_bnsums: 16-bit precisions only (fp32 keeps the separate reduce pass)");
+  FU_REQUIRE(dy && w_oihw && dx && y && bn_a && bn_b && mean && invstd && sum_gm && sum_gmx, "fu_op_conv3x3_dgrad_bnsums: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  TmpBuf wd, part;
+  FU_TRY(wd.get(conv3x3_pack_elems(p, C0, Cout) * fu_elem_size(precision)));
+  FU_TRY(launch_pack_conv3x3(p, w_oihw, Cout, C0, C0, nullptr, wd.p, s));
+  const int64_t cap = (int64_t)B * ceil_div(H, 16) * ceil_div(W, 16) * C0 * 2;
+  FU_TRY(part.get((size_t)cap * sizeof(float)));
+  int tiles = 0;
+  BnbFuse f;
+  f.y = y; f.a = bn_a; f.b = bn_b; f.mean = mean; f.invstd = invstd;
+  f.part = (float*)part.p; f.max_elems = cap; f.tiles_out = &tiles;
+  g_bnb_fuse = f;
+  ConvIn in{dy, Cout, nullptr, nullptr, nullptr, 0};
+  const int st = launch_conv3x3(p, in, wd.p, nullptr, dx, C0, nullptr, 0, nullptr, nullptr, B, H, W, s);
+  g_bnb_fuse = BnbFuse();
+  if (st) return st;
+  if (tiles <= 0) {
+    set_error("fu_op_conv3x3_dgrad_bnsums: the kernel that ran does not emit the sums for this shape / dispatch");
+    return FU_ERR_UNSUPPORTED;
+  }
+  FU_TRY(perturb_bnb((float*)part.p, tiles, C0, s));
+  FU_TRY(collapse_partials((const float*)part.p, tiles, C0, sum_gm, sum_gmx, s));
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_op_head_bwd(int precision, const float* dlogits_nhwc, const void* y, const float* bn_a, const float* bn_b,
+                   const float* w, int C, int ncls, int64_t npix, void* g, float* dw, float* db, const float* mean,
+                   const float* invstd, float* sum_gm, float* sum_gmx, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  FU_REQUIRE(dlogits_nhwc && y && w && g && dw && db, "fu_op_head_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  TmpBuf part, bpart;
+  FU_TRY(part.get((size_t)head_bwd_partial_elems(C, ncls) * sizeof(float)));
+  const bool want = mean && invstd && sum_gm && sum_gmx;
+  const int64_t cap = (int64_t)2048 * C * 2;
+  int tiles = 0;
+  BnbFuse f;
+  if (want) {
+    FU_TRY(bpart.get((size_t)cap * sizeof(float)));
+    f.y = y; f.a = bn_a; f.b = bn_b; f.mean = mean; f.invstd = invstd;
+    f.part = (float*)bpart.p; f.max_elems = cap; f.tiles_out = &tiles;
+  }
+  FU_TRY(launch_head_bwd(p, dlogits_nhwc, y, bn_a, bn_b, w, C, ncls, npix, g, (float*)part.p, dw, db, s,
+                         want ? &f : nullptr));
+  if (want) {
+    if (tiles <= 0) {
+      set_error("fu_op_head_bwd: the head-backward kernel does not emit the sums in this precision");
+      return FU_ERR_UNSUPPORTED;
+    }
+    FU_TRY(perturb_bnb((float*)bpart.p, tiles, C, s));
+    FU_TRY(collapse_partials((const float*)bpart.p, tiles, C, sum_gm, sum_gmx, s));
+  }
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_op_bn_bwd(int precision, void* g, const void* y, int C, int B, int H, int W, const float* bn_a,
+                 const float* bn_b, const float* mean, const float* invstd, const void* g_pool, float* dgamma,
+                 float* dbeta, fu_stream stream) {
+  Prec p; FU_TRY(prec_of(precision, &p));
+  FU_REQUIRE(g && y && bn_a && bn_b && mean && invstd && dgamma && dbeta, "fu_op_bn_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * H * W;
+  TmpBuf part, coef, dbp, scr;
+  FU_TRY(part.get((size_t)bn_bwd_partial_elems(C, npix) * sizeof(float)));
+  FU_TRY(coef.get((size_t)C * 2 * sizeof(float)));
+  FU_TRY(dbp.get((size_t)bn_bwd_partial_elems(C, npix) * sizeof(float)));
+  FU_TRY(scr.get((size_t)reduce_scratch_elems(std::max(C, 64)) * sizeof(double)));
+  int ndb = 0;
+  FU_TRY(launch_bn_bwd(p, g, y, C, npix, bn_a, bn_b, mean, invstd, nullptr, dgamma, dbeta, (float*)part.p,
+                       (float*)coef.p, (float*)dbp.p, &ndb, (double*)scr.p, s, g_pool, B, H, W, 0));
+  FU_HIP_CHECK(hipStreamSynchronize(s));
+  return FU_OK;
+}
+
+int fu_test_get_buffer(fu_ctx* c, int block, int which, void** ptr, int64_t* elems) {
+  FU_REQUIRE(c && ptr && elems, "fu_test_get_buffer: null argument");
+  FU_REQUIRE(block >= 0 && block < c->nb, "fu_test_get_buffer: block %d outside 0..%d", block, c->nb - 1);
+  const Block& K = c->blk[block];
+  const int B = c->cfg.max_batch;
+  auto act = [&](int level, int C) { return (int64_t)B * c->Hs[level] * c->Ws[level] * C; };
+  switch (which) {
+    case 0: *ptr = K.c[0].y; *elems = act(K.c[0].level, K.c[0].cout); break;
+    case 1: *ptr = K.c[0].gy; *elems = act(K.c[0].level, K.c[0].cout); break;
+    case 2: *ptr = K.c[1].y; *elems = act(K.c[1].level, K.c[1].cout); break;
+    case 3: *ptr = K.c[1].gy; *elems = act(K.c[1].level, K.c[1].cout); break;
+    case 4: *ptr = K.g_pooled; *elems = K.kind == BK_DOWN ? act(K.level, K.c[0].cin_real) : 0; break;
+    case 5: *ptr = K.g_up; *elems = K.kind == BK_UP ? act(K.level, K.c[0].cin_real - c->ch[K.skip]) : 0; break;
+    default: set_error("fu_test_get_buffer: which must be 0..5"); return FU_ERR_INVALID;
+  }
+  return FU_OK;
+}
+
 }  // extern "C"
 
 extern "C" void fu_test_bnb_separate(int on) { g_bnb_separate = on ? 1 : 0; }
+extern "C" void fu_test_perturb_bnb_sums(float factor) { g_test_perturb_bnb = factor; }

@@ -209,7 +209,7 @@ int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStrea
 static inline int sync_world() { return (g_sync && g_sync->hook) ? g_sync->world : 1; }
 
 // fp16 mode: the gradient maps (fp16) carry a power-of-two loss scale S chosen on the device from max|dL/dlogits| at the
-// start of every backward (launch_loss_scale).  scale[0] = S, scale[1] = 1/S.  The three places that write PARAMETER
+// start of every backward (launch_loss_grad_eff).  scale[0] = S, scale[1] = 1/S.  The three places that write PARAMETER
 // gradients (weight-gradient transpose + bias tail, BN backward finalize, head backward finalize) multiply by 1/S, so the
 // flat gradient buffer always holds true gradients.  The API layer points g_grad_unscale at scale + 1 for the duration of
 // a backward call in fp16 mode; nullptr (fp32 / bf16) means 1.
@@ -229,7 +229,9 @@ struct BnbFuse {
   int* tiles_out = nullptr;
 };
 extern thread_local BnbFuse g_bnb_fuse;
-int launch_loss_scale(float* dlogits, int64_t n, float* partials /* >= 256 floats */, float* scale /* [2] */, hipStream_t s);
+// out = dlogits * (*up_scale_dev or 1) * (S or 1); scale != null (fp16): S chosen from max|dlogits * up| and written to scale[0..1]
+int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const float* up_scale_dev,
+                         float* partials /* >= 256 floats */, float* scale /* [2] or null */, hipStream_t s);
 
 // ---- kernel launchers (implemented in the .hip files) ----------------------------------------
 // All pointers are device pointers; T-typed buffers are `void*` + Prec.
@@ -384,7 +386,6 @@ int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int
                           float* mean_out, float* std_out, hipStream_t s);
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
-int launch_scale_by_device_scalar(float* x, int64_t n, const float* scale_dev, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                 double eps, int64_t step, double grad_scale, hipStream_t s);
 

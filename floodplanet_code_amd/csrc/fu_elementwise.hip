@@ -634,8 +634,10 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   const bool pool = g_pool != nullptr;     // the max-pool backward of this tensor is folded into the two passes
   if (pool) {
     FU_REQUIRE((int64_t)B * H * W == npix && BNB_THREADS % (C >> 2) == 0, "bn_bwd (pooled): bad geometry");
-    FU_REQUIRE(npix < ((int64_t)1 << 31) && (int64_t)B * ((H + 1) / 2) * (int64_t)((W + 1) / 2) * ((W + 1) / 2) < ((int64_t)1 << 32),
-               "bn_bwd (pooled): more than 2^31 pixels");
+    // both fast_div decodes of k_bn_bwd_pool need n * d < 2^32: windows / Ww and (windows / Ww) / Hw
+    FU_REQUIRE(npix < ((int64_t)1 << 31) && (int64_t)B * ((H + 1) / 2) * (int64_t)((W + 1) / 2) * ((W + 1) / 2) < ((int64_t)1 << 32) &&
+                   (int64_t)B * ((H + 1) / 2) * (int64_t)((H + 1) / 2) < ((int64_t)1 << 32),
+               "bn_bwd (pooled): tensor too large for the 32-bit window decode");
     if (p == PREC_F32) launch_bn_bwd_pool_t<float>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
     else launch_bn_bwd_pool_t<f16_t>(false, nb, sh1, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, partials);
@@ -1931,7 +1933,8 @@ __global__ __launch_bounds__(256) void k_tile_stats(AsmSrcs S, int Ctot, int H, 
   int si = 0;
   for (int k = 1; k < S.n; ++k) si = c >= S.coff[k] ? k : si;
   const float* plane = S.p[si] + ((int64_t)b * S.c[si] + (c - S.coff[si])) * H * W;
-  const int h = vh ? vh[b] : H, w = vw ? vw[b] : W;
+  // (the crop sizes come from device memory: clamp, an oversized or negative entry must not read past the plane)
+  const int h = vh ? min(max(vh[b], 0), H) : H, w = vw ? min(max(vw[b], 0), W) : W;
   const int n = h * w;
   auto block_sum = [&](double v) {
     sm[threadIdx.x] = v;
@@ -1967,7 +1970,7 @@ __global__ void k_assemble_tiles(AsmSrcs S, int Ctot, int H, int W, const int* _
     const int b = (int)(r / Ctot);
     int si = 0;
     for (int k = 1; k < S.n; ++k) si = c >= S.coff[k] ? k : si;
-    const bool inside = y < (vh ? vh[b] : H) && x < (vw ? vw[b] : W);
+    const bool inside = y < (vh ? min(max(vh[b], 0), H) : H) && x < (vw ? min(max(vw[b], 0), W) : W);
     float v = pad_value;
     if (inside) {
       v = S.p[si][(((int64_t)b * S.c[si] + (c - S.coff[si])) * H + y) * W + x];
@@ -2113,9 +2116,14 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp16 loss scale (fu_common.h, g_grad_unscale): S = 2^k with max|dl| * S in [2^5, 2^6) -- three decades of headroom to
-// fp16's 65504 for what the backward chain multiplies on top, while the bulk of the gradient maps stays in fp16's normal
-// range.  Chosen from the data on the device (no host read, any loss, any upstream scale), applied in place.
+// The gradient the head backward consumes: eff = dlogits * up * S, written OUT OF PLACE (the stored loss gradient stays as
+// fu_loss_* left it, so a second backward of the same loss -- retain_graph, fu_backward_block(0) twice -- sees the same
+// input; in place, the second call would have found max|dl| already in [32, 64), chosen S = 1 and unscaled by 1).
+//   up: optional device scalar, the upstream gradient autograd hands to loss.backward() (fu_scale_loss_grad);
+//   S:  fp16 mode only (scale != null): 2^k with max|dl * up| * S in [2^5, 2^6) -- three decades of headroom to fp16's
+//       65504 for what the backward chain multiplies on top, while the bulk of the gradient maps stays in fp16's normal
+//       range; chosen from the data on the device (no host read, any loss, any upstream scale).  scale[0] = S,
+//       scale[1] = 1/S (fu_common.h, g_grad_unscale).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_absmax_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
   __shared__ float sm[4];
@@ -2130,39 +2138,38 @@ __global__ __launch_bounds__(256) void k_absmax_partial(const float* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
-__global__ __launch_bounds__(256) void k_loss_scale_apply(float* __restrict__ x, int64_t n, const float* __restrict__ partials,
-                                                          int nPart, float* __restrict__ scale) {
+__global__ __launch_bounds__(256) void k_loss_grad_eff(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                       const float* __restrict__ partials, int nPart,
+                                                       const float* __restrict__ up, float* __restrict__ scale) {
   __shared__ float sm[4];
-  float m = threadIdx.x < nPart ? partials[threadIdx.x] : 0.f;      // nPart <= 256
+  const float upv = up ? *up : 1.f;
+  float f = upv;
+  if (scale) {                                                        // uniform
+    float m = threadIdx.x < nPart ? partials[threadIdx.x] : 0.f;      // nPart <= 256
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-  int e = 0;
-  if (m > 0.f) { (void)frexpf(m, &e); e = 6 - e; }                  // m = f * 2^e', f in [0.5, 1)  ->  m * 2^(6 - e') in [32, 64)
-  e = min(max(e, -60), 60);
-  const float S = ldexpf(1.f, e);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = ldexpf(1.f, -e); }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= S;
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) * fabsf(upv);
+    int e = 0;
+    if (m > 0.f && m <= 3.0e38f) { (void)frexpf(m, &e); e = 6 - e; }  // m = f * 2^e', f in [0.5, 1)  ->  m * 2^(6 - e') in [32, 64)
+    e = min(max(e, -60), 60);
+    const float S = ldexpf(1.f, e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = ldexpf(1.f, -e); }
+    f = upv * S;                                                      // a power of two: no extra rounding
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x[i] * f;
 }
-int launch_loss_scale(float* dlogits, int64_t n, float* partials, float* scale, hipStream_t s) {
-  const int g = grid_for(n, 256 * 16, 256);
-  hipLaunchKernelGGL(k_absmax_partial, dim3(g), dim3(256), 0, s, dlogits, n, partials);
-  FU_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_loss_scale_apply, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, s, dlogits, n, partials, g, scale);
-  FU_LAUNCH_CHECK();
-  return 0;
-}
-
-// x[i] *= *scale_dev (the upstream gradient of the loss, a device scalar: no host read)
-__global__ void k_scale_by_device_scalar(float* __restrict__ x, int64_t n, const float* __restrict__ scale_dev) {
-  const float sc = *scale_dev;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] *= sc;
-}
-int launch_scale_by_device_scalar(float* x, int64_t n, const float* scale_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_scale_by_device_scalar, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, x, n, scale_dev);
+int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const float* up_scale_dev, float* partials,
+                         float* scale, hipStream_t s) {
+  int g = 0;
+  if (scale) {
+    g = grid_for(n, 256 * 16, 256);
+    hipLaunchKernelGGL(k_absmax_partial, dim3(g), dim3(256), 0, s, dlogits, n, partials);
+    FU_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_loss_grad_eff, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, s, dlogits, out, n, partials, g,
+                     up_scale_dev, scale);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -427,16 +427,38 @@ def _check_generation(ctx):
             "before the next training forward.")
 
 
-def _return_param_grads(m: "HipUNet"):
-    """Gradients of the HIP backward as autograd results.  Fast path (every p.grad is None, i.e. right after
-    optimizer.zero_grad(set_to_none=True), what Lightning and torch >= 2.0 do): point p.grad at the parameter's slice of
-    the flat gradient buffer the kernels have just written and hand autograd nothing to accumulate -- no 74 clones, no 74
-    accumulations, and HipAdam finds the gradients where fu_adam_step reads them.  Otherwise (a gradient is already
-    there: accumulation over several backward calls) return copies and let autograd add them."""
-    if all(p.grad is None for _, p, _, _ in m._table):
-        m.attach_grads()
-        return (None,) * len(m._table)
-    return tuple(g.clone() for g in m.grad_views())
+def _save_accumulated(m: "HipUNet"):
+    """Before fu_backward overwrites the flat gradient buffer: if some p.grad ALIASES its slice of that buffer (the state
+    the fast path of _return_param_grads leaves behind, also after zero_grad(set_to_none=False)), the values about to be
+    overwritten are gradients autograd is expected to accumulate into -- keep a copy.  Returns (saved flat buffer or None,
+    per-parameter alias flags)."""
+    views = m.grad_views()
+    alias = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for (_, p, _, _), v in zip(m._table, views)]
+    return (m._flat_grad.clone() if any(alias) else None), alias
+
+
+def _return_param_grads(m: "HipUNet", saved, alias):
+    """Gradients of the HIP backward as autograd results.
+    * p.grad is None (right after optimizer.zero_grad(set_to_none=True), what Lightning and torch >= 2.0 do): point p.grad at
+      the parameter's slice of the flat gradient buffer the kernels have just written and hand autograd nothing to
+      accumulate -- no 74 clones, no 74 accumulations, and HipAdam finds the gradients where fu_adam_step reads them.
+    * p.grad aliases that slice (a second backward before the optimiser step: gradient accumulation): the kernels have just
+      overwritten the accumulated value; add the saved copy back on the device, p.grad then holds old + new, and again
+      nothing is returned for autograd to add (returning a clone here would make autograd add it INTO the aliased slice:
+      2 * new instead of old + new).
+    * p.grad lives elsewhere (set by the user): return a copy and let autograd accumulate into it."""
+    views = m.grad_views()
+    out = []
+    for (_, p, off, n), v, al in zip(m._table, views, alias):
+        if p.grad is None:
+            p.grad = v
+            out.append(None)
+        elif al:
+            v.add_(saved[off:off + n].view(p.shape))
+            out.append(None)
+        else:
+            out.append(v.clone())
+    return tuple(out)
 
 
 class _UNetFn(torch.autograd.Function):
@@ -454,8 +476,9 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         m = ctx.module
         _check_generation(ctx)
+        saved, alias = _save_accumulated(m)
         m._backward_raw(dlogits.contiguous().float(), ctx.device)
-        return (None, None) + _return_param_grads(m)
+        return (None, None) + _return_param_grads(m, saved, alias)
 
 
 class _UNetLossFn(torch.autograd.Function):
@@ -480,8 +503,9 @@ class _UNetLossFn(torch.autograd.Function):
         # the upstream gradient of the loss (ones for a plain loss.backward()) scales dL/dlogits once, on the device
         dl = dloss.detach().reshape(()).to(device=ctx.device, dtype=torch.float32)
         check(_lib.load().fu_scale_loss_grad(m._ctx, ptr(dl), m._stream(ctx.device)))
+        saved, alias = _save_accumulated(m)
         m._backward_raw(None, ctx.device)
-        return (None, None, None, None, None, None, None) + _return_param_grads(m)
+        return (None, None, None, None, None, None, None) + _return_param_grads(m, saved, alias)
 
 
 class HipAdam(torch.optim.Adam):
@@ -516,8 +540,9 @@ class HipAdam(torch.optim.Adam):
         if any(p.grad is None for _, p, _, _ in net._table):
             raise RuntimeError("HipAdam.step(): a parameter has no gradient (the fused kernel updates all of them)")
         # gradients that autograd accumulated outside the flat buffer (the slow path of _return_param_grads) come home
-        if net._table[0][1].grad.data_ptr() != grads[0].data_ptr():
-            torch._foreach_copy_(grads, [p.grad for _, p, _, _ in net._table])
+        outside = [(g, p.grad) for (_, p, _, _), g in zip(net._table, grads) if p.grad.data_ptr() != g.data_ptr()]
+        if outside:
+            torch._foreach_copy_([a for a, _ in outside], [b for _, b in outside])
         g = self.param_groups[0]
         self._step += 1
         net.adam_step(g["lr"], self._step, g["betas"], g["eps"])

@@ -148,9 +148,11 @@ int fu_backward(fu_ctx* ctx, const float* dlogits, fu_stream stream);
  * (default) as described; mode 2: fu_backward_block does not join -- the caller calls fu_backward_join(stream) before
  * it consumes gradients on `stream` (e.g. once per all-reduce bucket instead of once per block). */
 int fu_set_side_stream(fu_ctx* ctx, int mode);
-/* Multiply the stored loss gradient (dL/dlogits of the last fu_loss_* call) by the device scalar *scale_dev: the
- * upstream gradient autograd hands to `loss.backward()` (fit.py:95-97), applied once to the logits gradient instead of
- * to every parameter gradient, without a host read. */
+/* The upstream gradient autograd hands to `loss.backward()` (fit.py:95-97) as a device scalar: the next backward
+ * multiplies the stored loss gradient (dL/dlogits of the last fu_loss_* call) by *scale_dev on its way into the head --
+ * once, on the logits gradient, instead of on every parameter gradient, and without a host read.  The stored gradient is
+ * not modified: repeating the call replaces the factor, repeating the backward (retain_graph) repeats the result; the
+ * factor is dropped by the next fu_forward / fu_loss_* call. */
 int fu_scale_loss_grad(fu_ctx* ctx, const float* scale_dev, fu_stream stream);
 int fu_backward_join(fu_ctx* ctx, fu_stream stream);
 
@@ -259,6 +261,16 @@ void fu_test_bnb_separate(int on);
  * bit-identical.  Process-wide. */
 void fu_test_force_full_taps(int on);
 
+/* Testing hook: every BatchNorm-backward pair of sums that a producer kernel emitted (row-stationary dgrad epilogue, head
+ * backward) is multiplied by `factor` before it is consumed -- the negative control of the parity tests (a wrong fused sum
+ * must make them fail).  1 = off.  Process-wide. */
+void fu_test_perturb_bnb_sums(float factor);
+/* Testing hook: device pointer and element count (at max_batch) of one saved tensor of plan block `block` (0..4 = inc,
+ * down1..4; 5..8 = up1..4 for the plain UNet): which 0 = y of the first conv, 1 = its gradient buffer, 2 / 3 = the same
+ * for the second conv, 4 = dL/d(pooled input) (down blocks), 5 = dL/d(upsampled input) (up blocks).  Elements are of
+ * the context's precision. */
+int fu_test_get_buffer(fu_ctx* ctx, int block, int which, void** ptr, int64_t* elems);
+
 /* ---- single operators (per-op parity tests; NHWC device buffers of the context's precision) -- */
 /* element size of the activation type for `precision` */
 int fu_elem_size(int precision);
@@ -284,6 +296,28 @@ int fu_op_maxpool2(int precision, const void* src, const float* bn_a, const floa
 /* bilinear x2, align_corners=True, result zero-padded (F.pad) to [outH, outW] */
 int fu_op_upsample2(int precision, const void* src, const float* bn_a, const float* bn_b, void* dst, int B, int H,
                     int W, int C, int outH, int outW, fu_stream stream);
+
+/* The operators below exist for the code that only runs in the benched 16-bit dispatch (they are test hooks like the
+ * fu_test_* switches: no ABI promise).
+ * dgrad as fu_op_conv3x3_dgrad with ONE destination that is the output gradient of a BatchNorm+ReLU whose raw input is y
+ * [B,H,W,C0] and whose coefficients are bn_a / bn_b / mean / invstd: also returns that BatchNorm's backward sums
+ * sum_gm[c] = sum_p g*m and sum_gmx[c] = sum_p g*m*xhat (m = [a*y+b > 0], xhat = (y-mean)*invstd), taken from the conv
+ * kernel's epilogue (BnbFuse).  FU_ERR_UNSUPPORTED when the kernel that ran does not emit them (select the
+ * row-stationary kernel with fu_test_conv_tile_mode(3)). */
+int fu_op_conv3x3_dgrad_bnsums(int precision, const void* dy, int Cout, const float* w_oihw, void* dx, int C0,
+                               const void* y, const float* bn_a, const float* bn_b, const float* mean,
+                               const float* invstd, float* sum_gm, float* sum_gmx, int B, int H, int W,
+                               fu_stream stream);
+/* head backward (OutConv 1x1): g = dlogits * W (element type of `precision`), dw [ncls][C], db [ncls]; with mean / invstd /
+ * sum_gm / sum_gmx non-null also the BatchNorm-backward sums of g as above (16-bit precisions). */
+int fu_op_head_bwd(int precision, const float* dlogits_nhwc, const void* y, const float* bn_a, const float* bn_b,
+                   const float* w, int C, int ncls, int64_t npix, void* g, float* dw, float* db, const float* mean,
+                   const float* invstd, float* sum_gm, float* sum_gmx, fu_stream stream);
+/* BatchNorm + ReLU backward in place: g holds dL/d relu(bn(y)) on entry and dL/dy on return; g_pool (optional,
+ * [B,H/2,W/2,C]) = dL/d maxpool2(relu(bn(y))), whose backward is folded in (first-maximum tie rule). */
+int fu_op_bn_bwd(int precision, void* g, const void* y, int C, int B, int H, int W, const float* bn_a,
+                 const float* bn_b, const float* mean, const float* invstd, const void* g_pool, float* dgamma,
+                 float* dbeta, fu_stream stream);
 
 #ifdef __cplusplus
 }

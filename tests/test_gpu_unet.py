@@ -481,6 +481,39 @@ def test_backward_of_a_stale_forward_raises():
     assert all(p.grad is not None for p in net.parameters())
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_repeated_backward_of_one_loss_gives_the_same_gradients(prec):
+    """fu_backward twice after one fu_loss_ce (retain_graph, or fu_backward_block(0) called again): the stored loss gradient is
+    never modified, so the second backward reproduces the first bit for bit -- in fp16 too, where the first backward used to
+    leave the loss scale inside the stored gradient and the second one then picked scale 1 -- and the upstream factor of
+    fu_scale_loss_grad is applied once, not compounded."""
+    from floodplanet_code_amd import _lib
+    lib = _lib.load()
+    st = O.make_state(8, 3, 16, True, seed=1)
+    batch = O.make_batch(2, 8, 64, 64, seed=2)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    net = HipUNet(8, 3, base_channels=16, precision=prec)
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    net._forward_raw(x, True, want_logits=False)
+    net._loss_raw(t, 0, x.device)
+    net._backward_raw(None, x.device)
+    g_plain = net.flat_grads().clone()
+    four = torch.tensor(4.0, device=DEV)
+    for _ in range(2):                                  # setting the factor twice replaces it
+        _lib.check(lib.fu_scale_loss_grad(net._ctx, four.data_ptr(), net._stream(x.device)))
+    net._backward_raw(None, x.device)
+    g1 = net.flat_grads().clone()
+    net._backward_raw(None, x.device)
+    g2 = net.flat_grads().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert torch.equal(g1, g2)
+    # a power-of-two factor commutes with every rounding of the (linear) backward, and fp16's device-side loss scale comes
+    # out four times smaller for the four times larger gradient: the result is the plain gradient times four
+    assert rel(g1, 4.0 * g_plain) <= 1e-6
+
+
 def test_plugin_path_uses_fused_adam_and_keeps_torch_semantics():
     """configure_optimizers() returns HipAdam (one fused launch); the Lightning loop zero_grad / training_step / backward /
     step gives the same parameters as torch.optim.Adam driven through the same loop (FU_TORCH_ADAM=1), the upstream
@@ -519,21 +552,41 @@ def test_plugin_path_uses_fused_adam_and_keeps_torch_semantics():
             # worst element by 2 % of the 4 steps' travel, and the mean deviation by 0.1 % of it
             assert (pa - pb).abs().max().item() <= 0.02 * 4 * 1e-3, k
             assert (pa - pb).abs().mean().item() <= 0.001 * 4 * 1e-3, k
-    # upstream gradient and accumulation
+    # upstream gradient and accumulation over two DIFFERENT micro-batches (p.grad aliases the flat gradient buffer after
+    # the first backward; the second backward overwrites that buffer and must add the first gradient back)
+    batch_b = {k: v.to(DEV) for k, v in O.make_batch(2, 8, 64, 64, seed=17).items()}
     oa.zero_grad()
     (ma.training_step(batch, 0) * 3.0).backward()
     g3 = [p.grad.clone() for p in ma.parameters()]
     oa.zero_grad()
     ma.training_step(batch, 0).backward()
     g1 = [p.grad.clone() for p in ma.parameters()]
-    ma.training_step(batch, 0).backward()            # p.grad present -> accumulate
+    oa.zero_grad()
+    ma.training_step(batch_b, 0).backward()
+    gb = [p.grad.clone() for p in ma.parameters()]
+    assert any(rel(b, a) > 1e-2 for a, b in zip(g1, gb))          # really different gradients
+    oa.zero_grad()
+    ma.training_step(batch, 0).backward()
+    ma.training_step(batch_b, 0).backward()          # p.grad present (aliasing the flat buffer) -> accumulate
     g2 = [p.grad.clone() for p in ma.parameters()]
-    for (k, _), a, b, c in zip(ma.named_parameters(), g1, g2, g3):
+    oa.zero_grad(set_to_none=False)                  # zeroed in place: the next backward accumulates into zeros
+    ma.training_step(batch_b, 0).backward()
+    gz = [p.grad.clone() for p in ma.parameters()]
+    ext = [torch.full_like(p, 0.25) for p in ma.parameters()]    # user-owned .grad tensors outside the flat buffer
+    for p, e in zip(ma.parameters(), ext):
+        p.grad = e
+    ma.training_step(batch, 0).backward()
+    ge = [p.grad.clone() for p in ma.parameters()]
+    # (BatchNorm running statistics moved between the calls; the gradients do not depend on them in train mode)
+    for (k, _), a, b, c, d, z, e in zip(ma.named_parameters(), g1, g2, g3, gb, gz, ge):
         if is_dead_bias(k.replace("model.", "", 1)) or a.norm().item() < 1e-7:
             continue
-        assert rel(b, 2 * a) <= 1e-5, k
+        assert rel(b, a + d) <= 1e-5, k
         assert rel(c, 3 * a) <= 1e-5, k
+        assert rel(z, d) <= 1e-6, k
+        assert rel(e, a + 0.25) <= 1e-5, k
     oa.step()                                         # gradients accumulated outside the flat buffer are copied home
+    assert all(rel(v, e) <= 1e-6 for v, e in zip(ma.model.grad_views(), ge))
     sd = oa.state_dict()
     assert len(sd["state"]) == len(list(ma.parameters())) and sd["param_groups"][0]["lr"] == 1e-3
     m2, o2 = make(False)
