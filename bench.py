@@ -349,7 +349,7 @@ def main():
             net = net.to(dev).train()
         else:
             net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
-        trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank)
+        trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank, time_waits=world > 1)
 
     B, Cc, S = args.batch, args.channels, args.size
     g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -379,8 +379,14 @@ def main():
     # the timed region; FU_BENCH_EVENT_STRIDE=1 times them all, 0 none
     stride = int(os.environ.get("FU_BENCH_EVENT_STRIDE", "8"))
     sampled = 0
+    if world > 1 and getattr(trainer, "_reducer", None) is not None:
+        trainer._reducer.reset_timing()     # the exposed all-reduce waits of the TIMED steps only
+    # one event per step boundary on the compute stream (a record is ~1 us of host time and serialises nothing): the
+    # per-step durations behind `ms_per_step_median`; `value` stays the wall clock around all K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         on = stride > 0 and i % stride == 0
         if on:
@@ -389,8 +395,12 @@ def main():
         loss = trainer.step(x, target, 0)
         if on:
             _lib.check(lib.fu_profile_enable(net._ctx, 0))
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms_median = (step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
+                      0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])) if step_ms else None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -480,14 +490,37 @@ def main():
            "path": ("C ABI: DataParallelTrainer.step" if args.path == "cabi" else
                     "plugin: build_model('ms_model').training_step + loss.backward() + configure_optimizers().step()")}
     if world > 1:
+        # what actually ran, for whoever reads an N > 1 record later: the world torch.distributed reports after
+        # init_process_group (not the flag), the transport, the bucket plan and how long the compute stream stood still
+        # for all-reduces that backward did not cover
         cfg["backend"] = backend
+        cfg["world_size_seen"] = dist.get_world_size()
+        cfg["devices_visible"] = n_dev
         cfg["backward_chain"] = {0: "serial (one stream)", 1: "side stream, join per block",
                                  2: "side stream, join per all-reduce bucket"}[trainer._side_mode()]
+        if os.environ.get("FU_DP_SIDE_MODE") is not None:
+            cfg["backward_chain_forced_by_env"] = "FU_DP_SIDE_MODE=" + os.environ["FU_DP_SIDE_MODE"]
+        red = getattr(trainer, "_reducer", None)
+        if red is not None:
+            cfg["allreduce_bucket_bytes"] = red.bucket_bytes()
+            w = red.exposed_wait_ms()
+            if w is not None:
+                stat = torch.tensor([w["device_mean"], w["device_max"], w["host_mean"]], device=dev, dtype=torch.float64)
+                dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+                cfg["allreduce_exposed_wait_ms"] = {
+                    "rank0": {k: round(v, 4) if isinstance(v, float) else v for k, v in w.items()},
+                    "max_over_ranks": {"device_mean": round(stat[0].item(), 4), "device_max": round(stat[1].item(), 4),
+                                       "host_mean": round(stat[2].item(), 4)},
+                    "meaning": "per step: HIP events on the compute stream around BucketedReducer.finish() (the stream "
+                               "waits there for the buckets' all-reduces: what backward did not overlap), and the host time "
+                               "in the same call"}
     out = {
         "metric": (f"training tiles/sec ({S}x{S}x{Cc}ch UNet)" if args.model == "unet" else
                    f"training tiles/sec ({S}x{S}, {Cc}ch image + {args.aux} aux, late fusion)"),
         "value": round(value, 3), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "ms_per_step_median": round(step_ms_median, 3) if step_ms_median is not None else None,
+        "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": cfg,
         "loss": round(float(loss.item()), 6),

@@ -66,6 +66,7 @@ SIGNATURES = {
     "fu_bind_buffers": (_i, [_p, _p, _p, _p, _p, _p]),
     "fu_params_changed": (_i, [_p]),
     "fu_forward": (_i, [_p, _p, _i, _i, _p, _p]),
+    "fu_forward_srcs": (_i, [_p, C.POINTER(_p), C.POINTER(C.c_int32), _i, _i, _i, _p, _p]),
     "fu_loss_ce": (_i, [_p, _p, _i, _p, _p, _p, _p]),
     "fu_loss_bce_dice": (_i, [_p, _p, _i, _f, _p, _p]),
     "fu_backward": (_i, [_p, _p, _p]),

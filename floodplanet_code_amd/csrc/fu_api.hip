@@ -759,12 +759,18 @@ int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
   return 0;
 }
 
-int forward_impl(fu_ctx* c, const float* x, int B, bool training, float* logits_out, hipStream_t s) {
+int forward_impl(fu_ctx* c, const float* x, const SrcList* srcs, int B, bool training, float* logits_out,
+                 hipStream_t s) {
   const fu_config& f = c->cfg;
   if (c->packed_dirty) FU_TRY(repack(c, s));
-  for (int e = 0; e < c->nE; ++e)
-    FU_TRY(launch_nchw_to_nhwc(c->prec, x, c->xin[e], B, c->enc_ch[e], f.height, f.width, c->cin_pad0[e], s,
-                               f.n_channels, c->enc_coff[e]));
+  for (int e = 0; e < c->nE; ++e) {
+    if (srcs)     // several input tensors side by side (fu_forward_srcs): the concat happens inside the layout conversion
+      FU_TRY(launch_gather_nchw_to_nhwc(c->prec, *srcs, c->xin[e], B, c->enc_ch[e], f.height, f.width, c->cin_pad0[e],
+                                        c->enc_coff[e], s));
+    else
+      FU_TRY(launch_nchw_to_nhwc(c->prec, x, c->xin[e], B, c->enc_ch[e], f.height, f.width, c->cin_pad0[e], s,
+                                 f.n_channels, c->enc_coff[e]));
+  }
   for (int i = 0; i < c->nb; ++i) {
     Block& K = c->blk[i];
     if (c->fusion && i == 5 * c->nE) FU_TRY(fuse_forward(c, B, s));
@@ -1052,6 +1058,18 @@ int fu_create(const fu_config* cfg, fu_ctx** out) {
   if (st == 0 && c->cfg.bilinear && c->prec != fu::PREC_F32 && !getenv("FU_NO_SIDE_STREAM")) {
     int plo = 0, phi = 0;
     (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // plo = the lowest priority (numerically largest)
+#ifdef FU_EXPERIMENTS   // A/B knob: FU_SIDE_CU_RESERVE=k keeps k of every 8 CUs (mask bits i with i % 8 < k) out of the side stream
+    if (const char* e = getenv("FU_SIDE_CU_RESERVE")) {
+      const int k = atoi(e);
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; ++b) if (((w * 32 + b) % 8) >= k) mask[w] |= 1u << b;
+      }
+      if (hipExtStreamCreateWithCUMask(&c->side_def, 8, mask) != hipSuccess) c->side_def = nullptr;
+      if (c->side_def) setenv("FU_SIDE_PRIO_DEFAULT", "1", 1);   // one masked stream serves both modes
+    } else
+#endif
     if (hipStreamCreateWithFlags(&c->side_def, hipStreamNonBlocking) != hipSuccess) c->side_def = nullptr;
     if (c->side_def && !getenv("FU_SIDE_PRIO_DEFAULT") &&
         hipStreamCreateWithPriority(&c->side_lo, hipStreamNonBlocking, plo) != hipSuccess)
@@ -1163,7 +1181,25 @@ int64_t fu_exact_sync_bytes(const fu_ctx* c) {
 int fu_forward(fu_ctx* c, const float* x, int batch, int training, float* logits_out, fu_stream stream) {
   FU_TRY(check_fwd_args(c, x, batch));
   SyncScope sc(c, training != 0);   // eval-mode BN uses the running statistics: nothing to exchange
-  return forward_impl(c, x, batch, training != 0, logits_out, (hipStream_t)stream);
+  return forward_impl(c, x, nullptr, batch, training != 0, logits_out, (hipStream_t)stream);
+}
+
+int fu_forward_srcs(fu_ctx* c, const float* const* srcs, const int32_t* src_channels, int n_src, int batch, int training,
+                    float* logits_out, fu_stream stream) {
+  FU_REQUIRE(srcs && src_channels && n_src >= 1 && n_src <= 8, "fu_forward_srcs: 1..8 sources");
+  FU_TRY(check_fwd_args(c, srcs[0], batch));
+  SrcList S;
+  S.n = n_src;
+  int off = 0;
+  for (int k = 0; k < n_src; ++k) {
+    FU_REQUIRE(srcs[k] && src_channels[k] >= 1, "fu_forward_srcs: bad source %d", k);
+    S.p[k] = srcs[k]; S.c[k] = src_channels[k]; S.coff[k] = off; off += src_channels[k];
+  }
+  S.coff[n_src] = off;
+  FU_REQUIRE(off == c->cfg.n_channels, "fu_forward_srcs: the sources have %d channels in all, the model takes %d", off,
+             c->cfg.n_channels);
+  SyncScope sc(c, training != 0);
+  return forward_impl(c, nullptr, &S, batch, training != 0, logits_out, (hipStream_t)stream);
 }
 
 int fu_loss_ce(fu_ctx* c, const int64_t* target, int ignore_index, float* loss_out, int64_t* confusion_out,

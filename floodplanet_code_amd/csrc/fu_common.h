@@ -297,6 +297,11 @@ extern int g_bf16_force_cfg;
 int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H, int W, int c_pad, hipStream_t s,
                         int src_channels = 0, int src_channel_offset = 0);
 int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H, int W, int c_pad, hipStream_t s);
+// up to 8 fp32 NCHW tensors [B, c[k], H, W] taken side by side along the channel axis; coff = prefix sums of c
+struct SrcList { const float* p[8]; int c[8]; int coff[9]; int n; };
+// dst [B,H,W,c_pad] <- channels [ch_off, ch_off + C) of the virtual concatenation (zero padding above C)
+int launch_gather_nchw_to_nhwc(Prec p, const SrcList& S, void* dst, int B, int C, int H, int W, int c_pad, int ch_off,
+                               hipStream_t s);
 
 // BN: finalize forward statistics.  partials [nTiles][C][2]; count = B*H*W.
 // training: writes mean/invstd/a/b, updates running stats (momentum 0.1, unbiased var) and nbt.

@@ -1165,6 +1165,14 @@ static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
   return 0;
 }
 
+#ifdef FU_EXPERIMENTS
+static int wgrad_mode_env() {
+  static int m = -1;
+  if (m < 0) { const char* e = getenv("FU_WGRAD_MODE"); m = e ? atoi(e) : 0; }
+  return m;
+}
+#endif
+
 // upper bound of the slab size over the two configurations below
 int64_t conv3x3_wgrad_slab_elems_bf16(int Cin, int Cout, int B, int H, int W) {
   const int64_t npix = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
@@ -1191,6 +1199,10 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   // over the ping-pong one; the eight unwritten tap slabs reach only taps of dw_oihw that the caller never reads
   if (in.center_only && !g_bf16_force_full_taps && P.Cin > 64) st = launch_wgrad_cfg<4, 8, 1>(P, 256, s);
   else if (in.center_only && !g_bf16_force_full_taps) st = launch_wgrad_cfg<2, 8, 1>(P, 512, s);
+#ifdef FU_EXPERIMENTS   // A/B knob (tools/ab_*.sh): FU_WGRAD_MODE=1 the 256-thread 64 x 64 kernel everywhere (512 WGs), 2 = the same at 256 WGs
+  else if (wgrad_mode_env() == 1) st = launch_wgrad_cfg<2, 8>(P, 512, s);
+  else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, s);
+#endif
   else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
   else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);
   else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU

@@ -132,6 +132,46 @@ int launch_nchw_to_nhwc(Prec p, const float* src, void* dst, int B, int C, int H
   return 0;
 }
 
+// The same conversion from SEVERAL NCHW sources taken side by side along the channel axis (ef_model.py:28-44: the image and
+// the auxiliary maps; stacked sensors): destination channel c is channel ch_off + c of the virtual concatenation.  The
+// torch.concat copy of the reference disappears into the layout conversion the first conv needs anyway.  One thread per
+// (pixel, vector of V channels); plane reads are coalesced across the threads of a wave, one 16-byte store.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_nchw_to_nhwc(SrcList S, T* __restrict__ dst, int C, int HW, int cpad,
+                                                              int ch_off) {
+  constexpr int V = VecIO<T>::V;
+  const int p = blockIdx.x * 256 + threadIdx.x;        // pixel inside the sample
+  const int o = blockIdx.y, b = blockIdx.z;            // channel vector, sample
+  if (p >= HW) return;
+  float v[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = o * V + j;
+    v[j] = 0.f;
+    if (c < C) {
+      const int cg = ch_off + c;
+      int si = 0;
+      for (int k = 1; k < S.n; ++k) si = cg >= S.coff[k] ? k : si;
+      v[j] = S.p[si][((size_t)b * S.c[si] + (cg - S.coff[si])) * HW + p];
+    }
+  }
+  VecIO<T>::store(dst + ((size_t)b * HW + p) * cpad + o * V, v);
+}
+
+int launch_gather_nchw_to_nhwc(Prec p, const SrcList& S, void* dst, int B, int C, int H, int W, int c_pad, int ch_off,
+                               hipStream_t s) {
+  const int V = p == PREC_F32 ? 4 : 8;
+  FU_REQUIRE(c_pad % V == 0 && B <= 65535 && c_pad / V <= 65535, "gather_nchw_to_nhwc: bad geometry (c_pad %d, batch %d)", c_pad, B);
+  FU_REQUIRE(ch_off >= 0 && ch_off + C <= S.coff[S.n], "gather_nchw_to_nhwc: channels [%d, %d) outside the %d source channels",
+             ch_off, ch_off + C, S.coff[S.n]);
+  const dim3 g((unsigned)ceil_div(H * W, 256), (unsigned)(c_pad / V), (unsigned)B);
+  if (p == PREC_F32) hipLaunchKernelGGL(k_gather_nchw_to_nhwc<float>, g, dim3(256), 0, s, S, (float*)dst, C, H * W, c_pad, ch_off);
+  else if (p == PREC_BF16) hipLaunchKernelGGL(k_gather_nchw_to_nhwc<bf16_t>, g, dim3(256), 0, s, S, (bf16_t*)dst, C, H * W, c_pad, ch_off);
+  else hipLaunchKernelGGL(k_gather_nchw_to_nhwc<f16_t>, g, dim3(256), 0, s, S, (f16_t*)dst, C, H * W, c_pad, ch_off);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_nhwc_to_nchw(Prec p, const void* src, float* dst, int B, int C, int H, int W, int c_pad, hipStream_t s) {
   const int64_t total = (int64_t)B * C * H * W;
   const int g = grid_for(total, 256);
@@ -1921,11 +1961,10 @@ int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* 
 // (base_dataset.py:271-325) and multi-sensor channel concatenation (ef_model.py:28-44 / stacked sensors) of a whole batch
 // that is already in HBM, instead of per item in DataLoader workers.
 // ------------------------------------------------------------------------------------------------
-struct AsmSrcs { const float* p[8]; int c[8]; int coff[9]; int n; };
 
 // one block per (sample, channel): mean and POPULATION std (numpy .mean / .std, ddof = 0) over the valid crop, two passes
 // (the plane stays in L2), fp64 accumulation, fixed-order block reduction
-__global__ __launch_bounds__(256) void k_tile_stats(AsmSrcs S, int Ctot, int H, int W, const int* __restrict__ vh,
+__global__ __launch_bounds__(256) void k_tile_stats(SrcList S, int Ctot, int H, int W, const int* __restrict__ vh,
                                                     const int* __restrict__ vw, float* __restrict__ mean_o,
                                                     float* __restrict__ std_o) {
   __shared__ double sm[256];
@@ -1957,7 +1996,7 @@ __global__ __launch_bounds__(256) void k_tile_stats(AsmSrcs S, int Ctot, int H, 
 }
 
 // out[b][c][y][x] = inside the valid crop ? (src - mean[b][c]) / std[b][c] : pad_value
-__global__ void k_assemble_tiles(AsmSrcs S, int Ctot, int H, int W, const int* __restrict__ vh, const int* __restrict__ vw,
+__global__ void k_assemble_tiles(SrcList S, int Ctot, int H, int W, const int* __restrict__ vh, const int* __restrict__ vw,
                                  const float* __restrict__ mean, const float* __restrict__ stdv, int per_sample,
                                  float pad_value, float* __restrict__ out, int64_t total) {
 #pragma clang fp contract(off)      // image -= mean; image /= std: two roundings, as numpy does them
@@ -1988,7 +2027,7 @@ int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int
                           const int* vw, int norm_mode, const float* gmean, const float* gstd, float pad_value, float* out,
                           float* mean_out, float* std_out, hipStream_t s) {
   FU_REQUIRE(n_src >= 1 && n_src <= 8, "assemble: 1..8 sources (got %d)", n_src);
-  AsmSrcs S;
+  SrcList S;
   S.n = n_src;
   int off = 0;
   for (int k = 0; k < n_src; ++k) {

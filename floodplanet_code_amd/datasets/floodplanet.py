@@ -26,7 +26,7 @@ from .resize import resize_image
 from .tiff import read_tiff, tiff_size
 from .tiles import CropParams, get_crop_slices
 
-__all__ = ["FloodplanetTiles", "collate_tiles"]
+__all__ = ["FloodplanetTiles", "RawTileView", "collate_tiles", "collate_raw_tiles"]
 
 _N_CHANNELS = {"S2": {"RGB": 3, "RGB_NIR": 4, "ALL": 10}, "PS": {"RGB": 3, "RGB_NIR": 4, "ALL": 4},
                "S1": {"ALL": 2}, "L8": {"ALL": 7}}
@@ -239,6 +239,55 @@ class FloodplanetTiles(torch.utils.data.Dataset):
         if self.output_metadata if output_metadata is None else output_metadata:
             out["metadata"] = {"image_path": ex["image_path"], "crop_params": cp, "region_name": ex["region_name"]}
         return out
+
+
+    def raw_item(self, index) -> dict:
+        """The same example BEFORE `normalize` and `_add_buffer_to_image` (floodplanet.py:613-625): the scaled crop as it
+        comes out of the raster, [C, h, w] with h <= max_crop_height, w <= max_crop_width at the raster's edge, and the
+        padded target.  The per-tile normalisation, the zero padding to the nominal tile and the sensor concat then run on
+        the whole batch in HBM (`datasets.assemble.assemble_tiles`, C ABI fu_assemble_tiles) -- TileLoader(device_assembly=True)."""
+        ex = self.dataset[index]
+        cp: CropParams = ex["crop_params"]
+        image = self._load_crop_norm_image(ex["image_path"], cp, self.channels, [cp.og_height, cp.og_width])
+        target = self._load_label_image(ex["label_path"], cp.og_height, cp.og_width, cp)
+        target = self._add_buffer(target, cp.max_crop_height, cp.max_crop_width, constant_value=self.ignore_index)
+        out = {"raw": torch.from_numpy(np.ascontiguousarray(image)).float(),
+               "target": torch.from_numpy(np.ascontiguousarray(target)).long(),
+               "tile_hw": (cp.max_crop_height, cp.max_crop_width)}
+        if self.output_metadata:
+            out["metadata"] = {"image_path": ex["image_path"], "crop_params": cp, "region_name": ex["region_name"]}
+        return out
+
+
+class RawTileView(torch.utils.data.Dataset):
+    """FloodplanetTiles seen through raw_item (what DataLoader workers produce for the device-side assembly)."""
+
+    def __init__(self, tiles: FloodplanetTiles):
+        self.tiles = tiles
+
+    def __len__(self):
+        return len(self.tiles)
+
+    def __getitem__(self, index):
+        return self.tiles.raw_item(index)
+
+
+def collate_raw_tiles(items: List[dict]) -> dict:
+    """Raw crops of one batch in ONE zero-filled host buffer [B, C, H, W] (crop in the top-left corner, as the device kernel
+    expects it) + the valid sizes; the host neither normalises nor pads with meaning -- the filler is never read."""
+    H, W = items[0]["tile_hw"]
+    Cc = items[0]["raw"].shape[0]
+    raw = torch.zeros(len(items), Cc, H, W, dtype=torch.float32)
+    vh = torch.empty(len(items), dtype=torch.int32)
+    vw = torch.empty(len(items), dtype=torch.int32)
+    for b, it in enumerate(items):
+        h, w = it["raw"].shape[-2:]
+        raw[b, :, :h, :w] = it["raw"]
+        vh[b], vw[b] = h, w
+    out = {"raw": raw, "valid_h": vh, "valid_w": vw, "target": torch.stack([i["target"] for i in items])}
+    if "metadata" in items[0]:
+        out["metadata"] = [i["metadata"] for i in items]
+    return out
 
 
 def collate_tiles(items: List[dict]) -> dict:

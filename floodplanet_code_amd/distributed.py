@@ -55,12 +55,20 @@ class BucketedReducer:
     """Asynchronous bucketed sum all-reduce of a flat gradient buffer, driven by block completion."""
 
     def __init__(self, block_ranges: Sequence[Tuple[int, int]], world_size: int, group=None,
-                 cap_bytes: int = 16 << 20):
+                 cap_bytes: int = 16 << 20, timing: bool = False):
         self.world_size = world_size
         self.group = group
         self.buckets = plan_buckets(block_ranges, cap_bytes)
         self._by_last = {last: (off, n) for last, off, n in self.buckets}
         self._pending = []
+        # diagnostics (bench.py, world > 1): per step an event pair on the compute stream around the waits of finish() --
+        # the time the compute stream stands still for all-reduces that backward did not cover -- and the host time there
+        self.timing = timing
+        self._wait_events = []
+        self._host_wait_s = []
+
+    def bucket_bytes(self, elem_bytes: int = 4) -> List[int]:
+        return [n * elem_bytes for _, _, n in self.buckets]
 
     def block_done(self, flat_grad: torch.Tensor, block: int) -> None:
         if self.world_size <= 1 or block not in self._by_last:
@@ -72,16 +80,41 @@ class BucketedReducer:
                                              async_op=True))
 
     def finish(self) -> None:
+        timed = self.timing and self._pending and torch.cuda.is_available()
+        if timed:
+            import time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
         for w in self._pending:
-            w.wait()
+            w.wait()          # nccl: the current stream waits for the collective's stream; gloo: the host waits
+        if timed:
+            e1.record()
+            self._host_wait_s.append(time.perf_counter() - t0)
+            self._wait_events.append((e0, e1))
         self._pending.clear()
+
+    def exposed_wait_ms(self) -> Optional[dict]:
+        """Per-step time the compute stream was blocked in finish() (device events) and the host spent there; call after a
+        device synchronise.  None when nothing was timed."""
+        if not self._wait_events:
+            return None
+        dev = [a.elapsed_time(b) for a, b in self._wait_events]
+        host = [1e3 * t for t in self._host_wait_s]
+        dev_s, host_s = sorted(dev), sorted(host)
+        return {"steps": len(dev), "device_mean": sum(dev) / len(dev), "device_median": dev_s[len(dev) // 2],
+                "device_max": dev_s[-1], "host_mean": sum(host) / len(host), "host_median": host_s[len(host) // 2]}
+
+    def reset_timing(self) -> None:
+        self._wait_events.clear()
+        self._host_wait_s.clear()
 
 
 class DataParallelTrainer:
     """fwd + CE + block-wise bwd (+ overlapped all-reduce) + fused Adam on a HipUNet."""
 
     def __init__(self, net, lr: float, world_size: int = 1, rank: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None, cap_bytes: int = 16 << 20, exact: bool = False):
+                 group=None, cap_bytes: int = 16 << 20, exact: bool = False, time_waits: bool = False):
         """exact=False: DDP semantics (per-rank BN statistics and 1/N_valid, gradients averaged).
         exact=True: SyncBN statistics and a global N_valid (HipUNet.enable_exact_sync); the ranks together reproduce
         one device with world_size x the batch, gradients are summed (SURVEY.md 8(e) "exact mode")."""
@@ -91,6 +124,7 @@ class DataParallelTrainer:
         if self.exact:
             net.enable_exact_sync(world_size, group)
         self.step_count = 0
+        self.time_waits = time_waits
         self._reducer: Optional[BucketedReducer] = None
         self._synced = False
 
@@ -124,7 +158,8 @@ class DataParallelTrainer:
             net._backward_raw(None, x.device)
         else:
             if self._reducer is None:
-                self._reducer = BucketedReducer(net.block_ranges(), self.world_size, self.group, self.cap_bytes)
+                self._reducer = BucketedReducer(net.block_ranges(), self.world_size, self.group, self.cap_bytes,
+                                                timing=self.time_waits)
             lib = _lib.load()
             stream = net._stream(x.device)
             flat = net.flat_grads()

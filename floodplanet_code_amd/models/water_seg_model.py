@@ -9,7 +9,7 @@ names; the network, the loss, the backward pass and the metric counters run in l
     torchmetrics (absent; parity unpinned).
   * ``ignore_index=None`` is accepted and means "ignore nothing" (-100), where the reference's
     nn.CrossEntropyLoss(ignore_index=None) fails at call time.
-Extra keyword arguments (not in the reference): ``precision`` ('fp32' | 'bf16'), ``base_channels``.
+Extra keyword arguments (not in the reference): ``precision`` ('fp32' | 'bf16' | 'fp16'), ``base_channels``.
 """
 from __future__ import annotations
 
@@ -70,8 +70,12 @@ class WaterSegmentationModel(LightningModule):
     def _gather_input(self, batch):
         return batch['image']                            # water_seg_model.py:88
 
+    def _gather_sources(self, batch):
+        """What the network is fed: a tensor, or a list of tensors it sees side by side along C (EarlyFusionModel)."""
+        return self._gather_input(batch)
+
     def forward(self, batch):
-        return self.model(self._gather_input(batch))
+        return self.model(self._gather_sources(batch))
 
     def _set_model_to_train(self):
         self.model.train()
@@ -83,7 +87,7 @@ class WaterSegmentationModel(LightningModule):
         """forward + CE(ignore_index) + NaN guard + argmax + confusion counts in the fused kernels.  The fp32 NCHW logits
         are only written when someone needs them: training_step's image logging is disabled in the reference
         (`if False:`, water_seg_model.py:116), so the training path never does; the counts stay on the device."""
-        images = self._gather_input(batch)
+        images = self._gather_sources(batch)
         out = self.model.loss(images, batch['target'], self._loss_ignore, return_logits=want_logits)
         loss, output = out if want_logits else (out, None)
         counts = self.model.pop_confusion()

@@ -319,18 +319,31 @@ class HipUNet(nn.Module):
         return torch.cuda.current_stream(device).cuda_stream
 
     # ---------------------------------------------------------------- raw calls
-    def _forward_raw(self, x: torch.Tensor, training: bool, want_logits: bool = True) -> Optional[torch.Tensor]:
-        if x.dim() != 4 or x.shape[1] != self.n_channels:
-            raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
-        x = x.detach().contiguous().float()
-        B, _, H, W = x.shape
-        ctx = self._get_ctx(x.device, B, H, W)
+    def _forward_raw(self, x, training: bool, want_logits: bool = True) -> Optional[torch.Tensor]:
+        """x: the input tensor [B, n_channels, H, W], or a list / tuple of tensors [B, C_k, H, W] that the model sees side by
+        side along the channel axis (ef_model.py:28-44 concatenates them; here fu_forward_srcs gathers them inside the
+        NCHW -> NHWC conversion: no concatenated copy)."""
+        srcs = list(x) if isinstance(x, (list, tuple)) else [x]
+        if not srcs or any(t.dim() != 4 for t in srcs) or sum(t.shape[1] for t in srcs) != self.n_channels:
+            raise ValueError(f"expected input [B,{self.n_channels},H,W] (in one tensor or split along C), got "
+                             f"{[tuple(t.shape) for t in srcs]}")
+        srcs = [t.detach().contiguous().float() for t in srcs]
+        B, _, H, W = srcs[0].shape
+        dev = srcs[0].device
+        if any(t.shape[0] != B or t.shape[2:] != (H, W) or t.device != dev for t in srcs):
+            raise ValueError("all input tensors must share batch, tile size and device")
+        ctx = self._get_ctx(dev, B, H, W)
         lib = _lib.load()
         if training or self._eval_dirty:
             check(lib.fu_params_changed(ctx))
             self._eval_dirty = training  # a training step is followed by an optimiser update
-        logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=x.device) if want_logits else None
-        check(lib.fu_forward(ctx, ptr(x), B, int(training), ptr(logits), self._stream(x.device)))
+        logits = torch.empty(B, self.n_classes, H, W, dtype=torch.float32, device=dev) if want_logits else None
+        if len(srcs) == 1:
+            check(lib.fu_forward(ctx, ptr(srcs[0]), B, int(training), ptr(logits), self._stream(dev)))
+        else:
+            arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            chs = (C.c_int32 * len(srcs))(*[t.shape[1] for t in srcs])
+            check(lib.fu_forward_srcs(ctx, arr, chs, len(srcs), B, int(training), ptr(logits), self._stream(dev)))
         if training:
             self._generation += 1
         return logits
@@ -383,15 +396,15 @@ class HipUNet(nn.Module):
                                     float(dice_weight), *params)
             return out if return_logits else out[0]
         logits = self._forward_raw(x, self.training, want_logits=return_logits)
-        loss = self._loss_raw(target, ignore_index, x.device, kind, dice_weight)
+        loss = self._loss_raw(target, ignore_index, _device_of(x), kind, dice_weight)
         return (loss, logits) if return_logits else loss
 
     def train_step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int, kind: str = "ce",
                    dice_weight: float = 1.0) -> torch.Tensor:
         """forward + loss + backward without autograd; gradients land in the flat buffer / p.grad."""
         self._forward_raw(x, True, want_logits=False)
-        loss = self._loss_raw(target, ignore_index, x.device, kind, dice_weight)
-        self._backward_raw(None, x.device)
+        loss = self._loss_raw(target, ignore_index, _device_of(x), kind, dice_weight)
+        self._backward_raw(None, _device_of(x))
         self.attach_grads()
         return loss
 
@@ -416,6 +429,10 @@ class HipUNet(nn.Module):
             check(lib.fu_block_param_range(self._ctx, b, C.byref(o), C.byref(n)))
             out.append((o.value, n.value))
         return out
+
+
+def _device_of(x):
+    return (x[0] if isinstance(x, (list, tuple)) else x).device
 
 
 def _check_generation(ctx):
@@ -467,7 +484,7 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: HipUNet, x, *params):
         ctx.module = module
-        ctx.device = x.device
+        ctx.device = _device_of(x)
         out = module._forward_raw(x, True)
         ctx.generation = module._generation
         return out
@@ -487,12 +504,12 @@ class _UNetLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: HipUNet, x, target, ignore_index, want_logits, kind, dice_weight, *params):
         ctx.module = module
-        ctx.device = x.device
+        ctx.device = _device_of(x)
         logits = module._forward_raw(x, True, want_logits=want_logits)
         ctx.generation = module._generation
-        loss = module._loss_raw(target, ignore_index, x.device, kind, dice_weight)
+        loss = module._loss_raw(target, ignore_index, ctx.device, kind, dice_weight)
         if logits is None:
-            logits = torch.empty(0, device=x.device)
+            logits = torch.empty(0, device=ctx.device)
         ctx.mark_non_differentiable(logits)
         return loss, logits
 

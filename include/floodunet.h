@@ -10,7 +10,7 @@
  *   fu_create / fu_destroy      UNet(n_channels, n_classes, bilinear)        st_water_seg/models/unet.py:80-98
  *                               built by WaterSegmentationModel._build_model st_water_seg/models/water_seg_model.py:79-85
  *   fu_param_info / fu_bind_*   UNet.state_dict() / .parameters()            (state-dict keys of unet.py:6-98)
- *   fu_forward                  UNet.forward                                 st_water_seg/models/unet.py:100-111
+ *   fu_forward[_srcs]           UNet.forward (+ the early-fusion concat)     st_water_seg/models/unet.py:100-111, ef_model.py:28-44
  *                               (train: nn.BatchNorm2d batch statistics; eval: running statistics,
  *                                water_seg_model.py:92-96)
  *   fu_loss_ce                  nn.CrossEntropyLoss(ignore_index) + nan_to_num + argmax + metric counts
@@ -123,6 +123,14 @@ int fu_params_changed(fu_ctx* ctx);
 /* x: fp32 NCHW [batch, n_channels, height, width].  logits_out: fp32 NCHW [batch, n_classes, H, W] or NULL.
  * training != 0: batch-statistics BN, running buffers updated, activations kept for backward. */
 int fu_forward(fu_ctx* ctx, const float* x, int batch, int training, float* logits_out, fu_stream stream);
+
+/* The same with the input given as n_src (<= 8) fp32 NCHW tensors [batch, src_channels[k], H, W] that the model sees
+ * side by side along the channel axis (sum src_channels = n_channels): the reference's
+ * `torch.concat([images, dem, slope, ...], dim=1)` (ef_model.py:28-44) / stacked sensors (BASELINE configs[4]) without the
+ * concatenated copy -- the channels are gathered by the NCHW -> NHWC conversion the first conv needs anyway.  srcs /
+ * src_channels: HOST arrays. */
+int fu_forward_srcs(fu_ctx* ctx, const float* const* srcs, const int32_t* src_channels, int n_src, int batch,
+                    int training, float* logits_out, fu_stream stream);
 
 /* Loss on the logits of the last fu_forward.  target: int64 [batch, H, W].
  * loss_out: device fp32 scalar (mean over non-ignored pixels; 0 when every pixel is ignored).

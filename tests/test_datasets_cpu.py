@@ -205,3 +205,48 @@ def test_dataset_splits_and_errors(tree):
         FloodplanetTiles(root, "train", sp, sensor="S1", train_split_pct=1.5)
     with pytest.raises(NotImplementedError):
         FloodplanetTiles(root, "train", sp, sensor="S1", channels="RGB")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the item dicts against the reference's own crop grid / normalize / buffer functions (oracle/make_loader_golden.py)
+def loader_golden():
+    z = np.load(os.path.join(GOLD, "loader_golden.npz"))
+    return json.loads(bytes(z["meta"]).decode()), z
+
+
+def loader_tree(tmp_path, meta):
+    root = str(tmp_path / "loader_tree")
+    t = dict(meta["tree"])
+    t["regions"] = tuple(t["regions"])
+    make_floodplanet_tree(root, **t)
+    return root
+
+
+def item_key(md):
+    cp = md["crop_params"]
+    name = os.path.splitext(os.path.basename(md["image_path"]))[0]
+    return f"{md['region_name']}/{name}/{cp.h0}_{cp.w0}"
+
+
+@pytest.mark.parametrize("norm_mode", [None, "local"])
+def test_host_assembled_items_equal_the_reference_functions_fixture(tmp_path, norm_mode):
+    """Every crop of a synthetic tree (image raster at the label raster's size: no resampling takes part): TIFF reader ->
+    crop grid -> S1 scaling -> normalize -> edge buffer, against arrays produced by the reference's own get_crop_slices /
+    _crop_image / normalize / _add_buffer_to_image.  Same float32 operations -> bit-exact, 'local' statistics included."""
+    from floodplanet_code_amd.datasets import FloodplanetTiles, generate_image_slice_object
+    meta, z = loader_golden()
+    root = loader_tree(tmp_path, meta)
+    sp = generate_image_slice_object(meta["crop"]["height"], meta["crop"]["width"], meta["crop"]["stride"])
+    ds = FloodplanetTiles(root, "all", sp, eval_region=["RegA"], sensor="S1", ignore_index=meta["ignore_index"],
+                          norm_mode=norm_mode, output_metadata=True)
+    assert len(ds) == len(meta["items"])
+    seen = set()
+    for i in range(len(ds)):
+        it = ds[i]
+        k = item_key(it["metadata"])
+        seen.add(k)
+        np.testing.assert_array_equal(it["image"].numpy(), z[f"{k}/{norm_mode}/image"], err_msg=k)
+        np.testing.assert_array_equal(it["target"].numpy(), z[f"{k}/target"], err_msg=k)
+        np.testing.assert_array_equal(np.asarray(it["mean"]).reshape(-1), z[f"{k}/{norm_mode}/mean"], err_msg=k)
+        np.testing.assert_array_equal(np.asarray(it["std"]).reshape(-1), z[f"{k}/{norm_mode}/std"], err_msg=k)
+    assert seen == {f"{i['region']}/{i['name']}/{i['h0']}_{i['w0']}" for i in meta["items"]}

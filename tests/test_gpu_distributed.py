@@ -87,14 +87,19 @@ def test_two_rank_data_parallel_matches_single_process_average(tmp_path, backend
     assert ((res["p0"] - ref).norm() / ref.norm()).item() <= 2e-3
 
 
-def _worker_exact(rank, world, port, out_path):
+def _worker_exact(rank, world, port, out_path, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":      # one GPU per rank over RCCL: the 37 statistics all-reduces of a step are RCCL kernels too
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from floodplanet_code_amd.distributed import DataParallelTrainer
     from floodplanet_code_amd.unet import HipUNet
     from oracle import unet_oracle as O
-    dev = torch.device("cuda:0")
     net = HipUNet(8, 3, base_channels=16)
     net.load_state_dict(O.make_state(8, 3, 16, True, seed=0))
     net.to(dev).train()
@@ -108,13 +113,16 @@ def _worker_exact(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_exact_mode_two_ranks_reproduce_one_device_with_the_joint_batch(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_exact_mode_two_ranks_reproduce_one_device_with_the_joint_batch(tmp_path, backend):
     """SURVEY 8(e) "exact mode": SyncBN statistics + global N_valid -> 2 ranks x 2 tiles == 1 device x 4 tiles."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with two ranks needs two GPUs (the one-GPU test box rehearses the path over gloo)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "exact.pt")
-    mp.spawn(_worker_exact, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker_exact, args=(2, port, out, backend), nprocs=2, join=True)
     res = torch.load(out)
 
     from floodplanet_code_amd.unet import HipUNet
@@ -230,13 +238,16 @@ def _worker_nccl_one_rank(rank, world, port, out_path):
         tr = D.DataParallelTrainer(net, lr=1e-3, world_size=1, rank=0, cap_bytes=512 << 10)
         if force:
             net._forward_raw(x, True, want_logits=False)        # creates the context: block ranges need it
-            tr._reducer = D.BucketedReducer(net.block_ranges(), 2, None, tr.cap_bytes)   # world 2: do all-reduce
+            tr._reducer = D.BucketedReducer(net.block_ranges(), 2, None, tr.cap_bytes, timing=True)   # world 2: do all-reduce
             res["n_buckets"] = len(tr._reducer.buckets)
+            res["bucket_bytes"] = tr._reducer.bucket_bytes()
             res["side_mode"] = tr._side_mode()
         for _ in range(3):
             loss = tr.step(x, t, 0)
         torch.cuda.synchronize()
         res[tag] = (net.flat_parameters().cpu().clone(), float(loss.item()))
+        if force:
+            res["waits"] = tr._reducer.exposed_wait_ms()
     D._FORCE_BLOCKS = False
     torch.save(res, out_path)
     dist.destroy_process_group()
@@ -250,5 +261,9 @@ def test_block_wise_backward_under_one_nccl_rank_equals_plain_backward(tmp_path)
     mp.spawn(_worker_nccl_one_rank, args=(1, port, out), nprocs=1, join=True)
     res = torch.load(out)
     assert res["n_buckets"] >= 3 and res["side_mode"] == 2          # nccl: side stream on, caller joins
+    # the diagnostics bench.py reports for N > 1: bucket plan and the exposed wait of finish() per step
+    assert sum(res["bucket_bytes"]) == 4 * res["blocks"][0].numel() and len(res["bucket_bytes"]) == res["n_buckets"]
+    w = res["waits"]
+    assert w["steps"] == 3 and 0.0 <= w["device_mean"] <= w["device_max"] < 1e3 and w["host_mean"] >= 0.0
     assert res["blocks"][1] == res["plain"][1]
     assert torch.equal(res["blocks"][0], res["plain"][0])

@@ -788,8 +788,9 @@ def test_baseline_config4_512_tiles_with_dem_channel_mixed_precision_dice(prec):
                         ignore_index=-100, precision=p).to(DEV)
         assert m.model.n_channels == 9 and m.model.precision == p
         m._set_model_to_train()
-        x = m._gather_input(batch)
-        assert x.shape == (2, 9, 512, 512)
+        assert m._gather_input(batch).shape == (2, 9, 512, 512)
+        x = m._gather_sources(batch)             # [image, dem]: gathered by the first layout conversion, no concat copy
+        assert [tuple(v.shape) for v in x] == [(2, 8, 512, 512), (2, 1, 512, 512)]
         losses = []
         for step in range(1, 5):
             loss = m.model.train_step(x, batch["target"], -100, kind="bce_dice", dice_weight=1.0)
@@ -839,6 +840,81 @@ def test_convtranspose_variant_bf16_tracks_fp32():
     assert torch.isfinite(net.flat_grads()).all()
 
 
+@pytest.mark.parametrize("norm_mode", [None, "local"])
+def test_device_assembled_batches_equal_the_reference_functions_fixture(tmp_path, norm_mode):
+    """SURVEY 8(f) rank 1 + 4 on the data path: TIFF reader -> crop grid -> raw crops + valid sizes to the device ->
+    fu_assemble_tiles (per-tile normalise, zero padding of edge crops) -> batch, against the item dicts produced by the
+    reference's own get_crop_slices / _crop_image / normalize / _add_buffer_to_image on the same synthetic rasters
+    (oracle/make_loader_golden.py; 18 of the 24 crops are cut at the raster's edge).  norm_mode None: two float32
+    operations per element, exact; 'local': the statistics are accumulated in fp64 on the device and pairwise in float32
+    by numpy -> 1e-6 relative on mean / std, 3e-6 of the value range on the image."""
+    import json, os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from conftest import GOLDEN
+    from tools.tiff_writer import make_floodplanet_tree
+    from floodplanet_code_amd.datasets import FloodplanetTiles, TileLoader, generate_image_slice_object
+    z = np.load(os.path.join(GOLDEN, "loader_golden.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    t = dict(meta["tree"])
+    t["regions"] = tuple(t["regions"])
+    root = str(tmp_path / "tree")
+    make_floodplanet_tree(root, **t)
+    sp = generate_image_slice_object(meta["crop"]["height"], meta["crop"]["width"], meta["crop"]["stride"])
+    ds = FloodplanetTiles(root, "all", sp, eval_region=["RegA"], sensor="S1", ignore_index=meta["ignore_index"],
+                          norm_mode=norm_mode, output_metadata=True)
+    loader = TileLoader(ds, 4, DEV, shuffle=False, device_assembly=True)
+    seen = 0
+    for batch in loader:
+        assert batch["image"].device.type == "cuda" and batch["image"].dtype == torch.float32
+        for b, md in enumerate(batch["metadata"]):
+            cp = md["crop_params"]
+            k = f"{md['region_name']}/{os.path.splitext(os.path.basename(md['image_path']))[0]}/{cp.h0}_{cp.w0}"
+            ref = z[f"{k}/{norm_mode}/image"]
+            got = batch["image"][b].cpu().numpy()
+            if norm_mode is None:
+                np.testing.assert_array_equal(got, ref, err_msg=k)
+            else:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(1.0, np.abs(ref).max()), err_msg=k)
+            np.testing.assert_allclose(batch["mean"][b].cpu().numpy().reshape(-1), z[f"{k}/{norm_mode}/mean"], rtol=1e-6, atol=0)
+            np.testing.assert_allclose(batch["std"][b].cpu().numpy().reshape(-1), z[f"{k}/{norm_mode}/std"], rtol=1e-6, atol=0)
+            np.testing.assert_array_equal(batch["target"][b].cpu().numpy(), z[f"{k}/target"], err_msg=k)
+            seen += 1
+    assert seen == len(meta["items"]) == 24
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_multi_source_input_equals_the_concatenated_input(prec):
+    """ef_model.py:28-44 concatenates image and auxiliary maps; fu_forward_srcs gathers the same channels inside the NCHW ->
+    NHWC conversion instead.  Same values in the same channel slots -> logits, loss and gradients bit-identical, for the
+    plain UNet and for the late-fusion net (encoder windows straddling the source boundary)."""
+    from floodplanet_code_amd.latefusion import HipLateFusion
+    from collections import OrderedDict
+    batch = O.make_batch(2, 8, 64, 64, seed=3, extra=("dem", "slope"))
+    img, dem, slope, t = (batch[k].to(DEV) for k in ("image", "dem", "slope", "target"))
+    cat = torch.cat([img, dem, slope], 1)
+    torch.manual_seed(0)
+    nets = [HipUNet(10, 3, base_channels=16, precision=prec).to(DEV),
+            HipLateFusion(OrderedDict([("ms_image", 8), ("dem", 1), ("slope", 1)]), 3, base_channels=16, precision=prec).to(DEV)]
+    for net in nets:
+        net.train()
+        la, lga = net.loss(cat, t, 0, return_logits=True)
+        la.backward()
+        ga = net.flat_grads().clone()
+        net.zero_grad(set_to_none=True)
+        for parts in ([img, dem, slope], [img[:, :5], torch.cat([img[:, 5:], dem], 1), slope]):
+            lb, lgb = net.loss(parts, t, 0, return_logits=True)
+            lb.backward()
+            torch.cuda.synchronize()
+            assert torch.equal(lga, lgb) and la.item() == lb.item()
+            assert torch.equal(ga, net.flat_grads())
+            net.zero_grad(set_to_none=True)
+        net.eval()
+        with torch.no_grad():
+            assert torch.equal(net(cat), net([img, dem, slope]))
+    with pytest.raises(ValueError):
+        nets[0]([img, dem])                      # 9 channels for a 10-channel model
+
+
 def test_tiff_tiles_train_through_the_registry(tmp_path):
     """BASELINE configs[0] on rasters in the bundled sample's format (S1: 2-band float32 planar strips, uint8 labels at a
     higher resolution): TIFF decode -> Lanczos resample -> tile grid -> GPU augmentation -> registry model -> fit loop."""
@@ -853,7 +929,7 @@ def test_tiff_tiles_train_through_the_registry(tmp_path):
     tr = FloodplanetTiles(root, "train", sp, eval_region=["RegC"], sensor="S1", ignore_index=0)
     va = FloodplanetTiles(root, "valid", sp, eval_region=["RegC"], sensor="S1", ignore_index=0)
     assert len(tr) == 16 and len(va) == 8 and tr.n_channels == {"ms_image": 2}
-    train = TileLoader(tr, 2, DEV, shuffle=True, seed=0, transforms={}, ignore_index=0)
+    train = TileLoader(tr, 2, DEV, shuffle=True, seed=0, transforms={}, ignore_index=0, device_assembly=True)
     valid = TileLoader(va, 2, DEV)
     b = next(iter(train))
     assert b["image"].shape == (2, 2, 64, 64) and b["image"].device.type == "cuda" and b["target"].dtype == torch.int64
