@@ -50,6 +50,7 @@ def parse(argv=None):
                          "training_step(); loss.backward(); opt.step() (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the small HIP-vs-oracle training comparison (miou_vs_ref)")
+    ap.add_argument("--no-eval", action="store_true", help="skip the eval-forward / stitching side measurement")
     ap.add_argument("--no-serial-pass", action="store_true",
                     help="skip the extra un-timed pass that measures the dominant kernel without the side stream")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -230,45 +231,106 @@ def pmc_traffic(dtype, kernel, standard_workload):
     return None, f"traffic: no PMC summary under profiles/ was taken from these kernel sources (csrc_sha {sha})"
 
 
-def miou_vs_ref(dev, dtype):
-    """`mIoU vs ref` half of BASELINE.json's metric, on a bounded workload: the HIP path (this run's dtype, and fp32) and
-    the oracle (the reference's arithmetic, torch-CPU) train from the same seeded state on the same seeded tiles for the
-    same number of Adam steps; micro Jaccard over argmax with ignore_index (water_seg_model.py:46-63) of the eval-mode
-    predictions on those tiles, and the gaps."""
+MIOU_GOLDEN = os.path.join(ROOT, "tests", "golden", "miou_golden.json")
+
+
+def miou_vs_ref(dev, dtype, precisions=None):
+    """`mIoU vs ref` half of BASELINE.json's metric ("the HIP path vs the reference path trained on identical
+    tiles/seeds").  The reference side is tests/golden/miou_golden.json: the oracle (= the reference's arithmetic, pinned bit
+    for bit) trained at FULL width on 32 seeded 8-band 128x128 tiles of a task that has to be learnt for 100 Adam steps and
+    evaluated, in eval mode, on 16 HELD-OUT tiles (oracle/make_miou_golden.py, ~4 CPU-minutes: run in the build container).
+    Here the HIP path trains from the same state on the same tiles (this run's dtype, and fp32) and predicts the same
+    held-out tiles; reported: micro Jaccard over argmax with ignore_index (water_seg_model.py:46-63) and the gaps."""
     import torch
     from floodplanet_code_amd.metrics import SegmentationMetrics
     from floodplanet_code_amd.unet import HipUNet
     from oracle import unet_oracle as O
-    B, Cc, S, base, steps, lr, ii = 4, 8, 64, 16, 30, 1e-3, 0
-    st0 = O.make_state(Cc, 3, base, True, seed=5, nontrivial_bn=False)
-    batch = O.make_batch(B, Cc, S, S, seed=9)
-    # a learnable signal: band 0 carries the label (as fit.SyntheticTiles does)
-    batch["image"][:, 0] = 0.5 * batch["image"][:, 0] + 0.5 * (batch["target"] == 1).float()
+    gold = json.load(open(MIOU_GOLDEN))
+    c = gold["config"]
+    ii = c["ignore_index"]
+    st0 = O.make_state(c["channels"], 3, c["base"], True, seed=c["param_seed"], nontrivial_bn=False)
+    train = O.make_task_tiles(c["n_train"], c["channels"], c["size"], c["train_seed"], c["signal"])
+    held = O.make_task_tiles(c["n_heldout"], c["channels"], c["size"], c["heldout_seed"], c["signal"])
+    xt, tt = train["image"].to(dev), train["target"].to(dev)
+    xh, th = held["image"].to(dev), held["target"]
+    nb, bs = c["n_train"] // c["batch"], c["batch"]
 
     def jac(pred, target):
         return SegmentationMetrics(3, ignore_index=ii)(pred.cpu(), target.cpu())["MulticlassJaccardIndex"].item()
 
-    st = {k: v.clone() for k, v in st0.items()}
-    opt = O.new_adam_state(st)
-    for _ in range(steps):
-        O.train_step(st, opt, batch, ii, lr)
-    out = {"oracle_fp32": jac(O.eval_forward(st, batch).argmax(1), batch["target"])}
-    x, t = batch["image"].to(dev), batch["target"].to(dev)
-    for name in dict.fromkeys(["fp32", PRECISION[dtype]]):
-        net = HipUNet(Cc, 3, base_channels=base, precision=name)
+    out, losses = {}, {}
+    names = precisions or list(dict.fromkeys(["fp32", PRECISION[dtype]]))
+    for name in names:
+        net = HipUNet(c["channels"], 3, base_channels=c["base"], precision=name)
         net.load_state_dict(st0)
         net.to(dev).train()
-        for step in range(1, steps + 1):
-            net.train_step(x, t, ii)
-            net.adam_step(lr, step)
+        last = None
+        for step in range(c["steps"]):
+            k = step % nb
+            last = net.train_step(xt[k * bs:(k + 1) * bs], tt[k * bs:(k + 1) * bs], ii)
+            net.adam_step(c["lr"], step + 1)
         net.eval()
         with torch.no_grad():
-            out[f"hip_{name}"] = jac(net(x).argmax(1), t)
-    ref = out["oracle_fp32"]
-    return {"workload": f"{steps} Adam steps (lr {lr}) on {B} seeded {Cc}ch {S}x{S} tiles, base width {base}, "
-                        f"ignore_index {ii}; micro Jaccard of the eval-mode argmax on the same tiles",
-            "jaccard": {k: round(v, 4) for k, v in out.items()},
-            "gap_vs_ref": {k: round(v - ref, 4) for k, v in out.items() if k != "oracle_fp32"}}
+            ph = torch.cat([net(xh[k:k + bs]).argmax(1) for k in range(0, xh.shape[0], bs)])
+            pt = torch.cat([net(xt[k:k + bs]).argmax(1) for k in range(0, xt.shape[0], bs)])
+        out[f"hip_{name}"] = {"heldout": jac(ph, th), "train": jac(pt, tt)}
+        losses[f"hip_{name}"] = float(last.item())
+    ref_h, ref_t = gold["jaccard_heldout"], gold["jaccard_train"]
+    return {"workload": f"{c['steps']} Adam steps (lr {c['lr']}, batch {bs}) on {c['n_train']} seeded {c['channels']}ch "
+                        f"{c['size']}x{c['size']} tiles, full width (base {c['base']}), ignore_index {ii}; micro Jaccard of the "
+                        f"eval-mode argmax on {c['n_heldout']} held-out tiles (and on the training tiles)",
+            "reference": "tests/golden/miou_golden.json (oracle/make_miou_golden.py: the reference's arithmetic, torch-CPU fp32)",
+            "jaccard_heldout": {"oracle_fp32": round(ref_h, 4), **{k: round(v["heldout"], 4) for k, v in out.items()}},
+            "jaccard_train": {"oracle_fp32": round(ref_t, 4), **{k: round(v["train"], 4) for k, v in out.items()}},
+            "final_train_loss": {"oracle_fp32": round(gold["loss_curve"][-1], 5), **{k: round(v, 5) for k, v in losses.items()}},
+            "gap_vs_ref": {k: round(v["heldout"] - ref_h, 4) for k, v in out.items()}}
+
+
+def eval_forward_bench(net, dev, x, iters=20):
+    """Inference beside the training number (predict.py:198-347): eval-mode forward of the bench batch
+    (BatchNorm folded into the packed conv weights once, fu_forward(training = 0)) and the same followed by the
+    overlap-average stitching of every tile's softmax into a canvas (fu_stitch_add) + the final divide / argmax
+    (fu_stitch_finalize).  Not part of `value`."""
+    import torch
+    from floodplanet_code_amd.stitch import GpuImageStitcher
+    B, _, S, _ = x.shape
+    net.eval()
+    res = {}
+    with torch.no_grad():
+        for _ in range(3):
+            net._forward_raw(x, False, want_logits=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            net._forward_raw(x, False, want_logits=False)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / iters
+        res["forward_tiles_per_s"] = round(B / dt, 1)
+        res["forward_ms_per_batch"] = round(dt * 1e3, 3)
+        # tiles laid out on a 4 x 4 grid with half-tile overlap (stride S/2), as predict.py crops a raster
+        side = int(B ** 0.5)
+        H = W = S // 2 * (side + 1)
+        boxes = [((i // side) * S // 2, (i % side) * S // 2) for i in range(side * side)]
+        st = GpuImageStitcher(net, dev)
+        def once():
+            st.image_canvas.clear()
+            st.weight_canvas.clear()
+            net._forward_raw(x, False, want_logits=False)
+            for i, (h0, w0) in enumerate(boxes):
+                st.add_image(i, "r", (h0, w0, h0 + S, w0 + S), H, W)
+            return st.combine("r")
+        once()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            once()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / iters
+        res["forward_plus_stitch_tiles_per_s"] = round(len(boxes) / dt, 1)
+        res["forward_plus_stitch_ms_per_batch"] = round(dt * 1e3, 3)
+        res["stitch_canvas"] = [H, W]
+    net.train()
+    return res
 
 
 class _PluginStepper:
@@ -527,6 +589,8 @@ def main():
         "roofline": roof,
     }
     if rank == 0:
+        if world == 1 and args.model == "unet" and args.path == "cabi" and not args.no_eval:
+            out["eval"] = eval_forward_bench(net, dev, x)
         if world == 1 and not args.no_miou:
             out["miou_vs_ref"] = miou_vs_ref(dev, args.dtype)
         if not args.no_cpu_baseline and world == 1:

@@ -79,6 +79,7 @@ struct PackDesc {
   void* wf;
   void* wd;
   int tile_start, tiles_ci;   // bf16 tiled pack: first 32x32 (co x ci) tile of this layer, tiles along ci
+  const float* scale;         // eval pack: per-output-channel factor gamma * invstd of the BatchNorm behind the conv
 };
 constexpr int MAX_PACK = 32;
 struct PackTable { PackDesc d[MAX_PACK]; int n; int64_t total; int tiles; };
@@ -87,7 +88,7 @@ struct PackTable { PackDesc d[MAX_PACK]; int n; int64_t total; int tiles; };
 template <bool HALF> __device__ __forceinline__ unsigned short cvt16(float v) { return HALF ? f2h(v) : f2bf(v); }
 
 template <typename T, bool BF16_LAYOUT, bool HALF = false>
-__global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
+__global__ void k_pack_all(const float* __restrict__ params, PackTable tab, int use_scale) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tab.total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int l = 0;
@@ -108,7 +109,8 @@ __global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
       ci = (int)(r % D.cin_pad);
       tap = (int)(r / D.cin_pad);
     }
-    const float v = ci < D.cin_real ? w[((int64_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
+    float v = ci < D.cin_real ? w[((int64_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
+    if (use_scale) v *= D.scale[co];
     T* wf = (T*)D.wf;
     T* wd = (T*)D.wd;
     if (BF16_LAYOUT) {
@@ -126,7 +128,7 @@ __global__ void k_pack_all(const float* __restrict__ params, PackTable tab) {
 // wd: c_out); the element-wise kernel above reads with a 36-byte stride and writes 2-byte values 2*cout bytes apart
 // (142 us per step for the 17M-parameter UNet, 8x its HBM time).  Needs cout % 8 == 0 and cin_pad % 8 == 0.
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_pack_tiles_16(const float* __restrict__ params, PackTable tab) {
+__global__ __launch_bounds__(256) void k_pack_tiles_16(const float* __restrict__ params, PackTable tab, int use_scale) {
   constexpr int PITCH = 34;
   __shared__ unsigned short sT[9][32][PITCH];
   int l = 0;
@@ -140,7 +142,8 @@ __global__ __launch_bounds__(256) void k_pack_tiles_16(const float* __restrict__
     const int co_l = e / 288, r = e - co_l * 288;
     const int ci_l = r / 9, tap = r - ci_l * 9;
     const int co = co0 + co_l, ci = ci0 + ci_l;
-    const float v = (co < D.cout && ci < D.cin_real) ? w[((size_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
+    float v = (co < D.cout && ci < D.cin_real) ? w[((size_t)co * D.cin_real + ci) * 9 + tap] : 0.f;
+    if (use_scale && co < D.cout) v *= D.scale[co];
     sT[tap][co_l][ci_l] = cvt16<HALF>(v);
   }
   __syncthreads();
@@ -173,6 +176,23 @@ __global__ __launch_bounds__(256) void k_pack_tiles_16(const float* __restrict__
 constexpr float BN_EPS = 1e-5f;
 constexpr float BN_MOMENTUM = 0.1f;
 
+// Eval mode (water_seg_model.py:92-96, 138-158: BatchNorm on its running statistics): bn(conv(x)) is affine per output
+// channel, so it is folded into the conv once per parameter change -- packed weights times scale = gamma / sqrt(rv + eps),
+// bias' = scale * bias + (beta - rm * scale) -- and every consumer's activation prologue becomes relu(1 * y + 0).
+__global__ void k_bn_fold_eval(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, const float* __restrict__ bias,
+                               float eps, float* __restrict__ scale, float* __restrict__ fbias, float* __restrict__ a,
+                               float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  fbias[c] = fmaf(sc, bias[c], beta[c] - rm[c] * sc);
+  a[c] = 1.f;
+  b[c] = 0.f;
+}
+
 struct ParamInfo {
   std::string name;
   int ndim;
@@ -191,6 +211,7 @@ struct Conv {
   void* wf = nullptr;
   void* wd = nullptr;
   float *mean = nullptr, *invstd = nullptr, *a = nullptr, *b = nullptr, *coef = nullptr;
+  float *fold_scale = nullptr, *fold_bias = nullptr;   // eval pack (k_bn_fold_eval)
   void* y = nullptr;
   void* gy = nullptr;
   const void* pool_g = nullptr;   // backward: dL/d(maxpool(this output)), to be folded into this conv's BN backward
@@ -296,6 +317,7 @@ struct fu_ctx {
   float* RV = nullptr;
   int64_t* NBT = nullptr;
   bool packed_dirty = true;
+  bool packed_eval = false;       // the packed copies hold the eval-folded weights (BatchNorm inside) rather than the plain ones
   // owned
   Arena arena;
   std::vector<void*> extra_allocs;
@@ -515,6 +537,8 @@ int alloc_workspace(fu_ctx* c) {
       A.want(&v.a, v.cout * sizeof(float));
       A.want(&v.b, v.cout * sizeof(float));
       A.want(&v.coef, v.cout * 2 * sizeof(float));
+      A.want(&v.fold_scale, v.cout * sizeof(float));
+      A.want(&v.fold_bias, v.cout * sizeof(float));
       A.want(&v.wf, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
       if (!(K.role == 0 && j == 0)) A.want(&v.wd, conv3x3_pack_elems(c->prec, v.cin_pad, v.cout) * es);
       max_stats = std::max<int64_t>(max_stats, (int64_t)conv3x3_num_stat_tiles(c->prec, B, H, W) * v.cout * 2);
@@ -585,22 +609,38 @@ int alloc_workspace(fu_ctx* c) {
   return 0;
 }
 
-// arm the event pair for the next conv / wgrad launch
-void prof_arm(fu_ctx* c, int cls, double flops) {
+// the event pair for ONE conv / wgrad launch (empty when profiling is off): goes into that launch's ConvIn::opt.prof
+ProfSlot prof_arm(fu_ctx* c, int cls, double flops) {
   Profiler& pr = c->prof;
-  if (!pr.on) return;
-  if (pr.next + 2 > pr.pool.size()) { pr.overflow = true; return; }
+  ProfSlot ps;
+  if (!pr.on) return ps;
+  if (pr.next + 2 > pr.pool.size()) { pr.overflow = true; return ps; }
   ProfRec r{cls, flops, pr.pool[pr.next], pr.pool[pr.next + 1]};
   pr.next += 2;
   pr.recs.push_back(r);
-  g_prof_slot.start = r.e0;
-  g_prof_slot.stop = r.e1;
+  ps.start = r.e0;
+  ps.stop = r.e1;
+  return ps;
 }
 
 inline float* P(fu_ctx* c, int idx) { return c->P + c->params[idx].off; }
 inline float* G(fu_ctx* c, int idx) { return c->G + c->params[idx].off; }
 
-int repack(fu_ctx* c, hipStream_t s) {
+int repack(fu_ctx* c, hipStream_t s, bool eval) {
+  if (FU_EXP_SKIP(8) && !c->pack_tabs.empty() && c->packed_eval == eval) { c->packed_dirty = false; return 0; }
+  const int use_scale = eval ? 1 : 0;
+  if (eval) {
+    for (int i = 0; i < c->nb; ++i)
+      for (int j = 0; j < 2; ++j) {
+        Conv& v = c->blk[i].c[j];
+        const int64_t off = c->bns[v.bn].off;
+        hipLaunchKernelGGL(k_bn_fold_eval, dim3(fu::ceil_div(v.cout, 64)), dim3(64), 0, s, v.cout, P(c, v.p_g),
+                           P(c, v.p_beta), c->RM + off, c->RV + off, P(c, v.p_b), BN_EPS, v.fold_scale, v.fold_bias, v.a,
+                           v.b);
+      }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("eval fold launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
+  }
   if (c->pack_tabs.empty()) {
     bool tiled_ok = true;
     for (int i = 0; i < c->nb; ++i)
@@ -624,6 +664,7 @@ int repack(fu_ctx* c, hipStream_t s) {
         d.w_off = c->params[v.p_w].off;
         d.cout = v.cout; d.cin_real = v.cin_real; d.cin_pad = v.cin_pad; d.pad_ = 0;
         d.wf = v.wf; d.wd = v.wd;
+        d.scale = v.fold_scale;
         start += (int64_t)9 * v.cin_pad * v.cout;
         d.tile_start = t.tiles;
         d.tiles_ci = fu::ceil_div(v.cin_pad, 32);
@@ -635,15 +676,15 @@ int repack(fu_ctx* c, hipStream_t s) {
   const int grid = 2048;
   for (const PackTable& t : c->pack_tabs) {
     if (c->prec == PREC_F32)
-      hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL((k_pack_all<float, false>), dim3(grid), dim3(256), 0, s, c->P, t, use_scale);
     else if (t.tiles > 0 && c->prec == PREC_BF16)
-      hipLaunchKernelGGL(k_pack_tiles_16<false>, dim3(t.tiles), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL(k_pack_tiles_16<false>, dim3(t.tiles), dim3(256), 0, s, c->P, t, use_scale);
     else if (t.tiles > 0)
-      hipLaunchKernelGGL(k_pack_tiles_16<true>, dim3(t.tiles), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL(k_pack_tiles_16<true>, dim3(t.tiles), dim3(256), 0, s, c->P, t, use_scale);
     else if (c->prec == PREC_BF16)
-      hipLaunchKernelGGL((k_pack_all<bf16_t, true, false>), dim3(grid), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL((k_pack_all<bf16_t, true, false>), dim3(grid), dim3(256), 0, s, c->P, t, use_scale);
     else
-      hipLaunchKernelGGL((k_pack_all<bf16_t, true, true>), dim3(grid), dim3(256), 0, s, c->P, t);
+      hipLaunchKernelGGL((k_pack_all<bf16_t, true, true>), dim3(grid), dim3(256), 0, s, c->P, t, use_scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("pack launch failed: %s", hipGetErrorString(e)); return FU_ERR_HIP; }
   }
@@ -661,6 +702,7 @@ int repack(fu_ctx* c, hipStream_t s) {
     }
   }
   c->packed_dirty = false;
+  c->packed_eval = eval;
   return 0;
 }
 
@@ -697,19 +739,18 @@ ConvIn conv_input(fu_ctx* c, int i, int j) {
 int conv_fwd(fu_ctx* c, int i, int j, int B, bool training, hipStream_t s) {
   Conv& v = c->blk[i].c[j];
   const int H = c->Hs[v.level], W = c->Ws[v.level];
-  const ConvIn in = conv_input(c, i, j);
+  ConvIn in = conv_input(c, i, j);
   int nt = 0;
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
-  prof_arm(c, FU_K_CONV3X3, fl);
-  FU_TRY(launch_conv3x3(c->prec, in, v.wf, P(c, v.p_b), v.y, v.cout, nullptr, 0, training ? c->stats : nullptr, &nt, B,
-                        H, W, s));
+  in.opt.prof = prof_arm(c, FU_K_CONV3X3, fl);
+  // eval: the packed weights and v.fold_bias already contain the BatchNorm (repack(eval)); y IS bn(conv(x)), v.a / v.b = 1 / 0
+  FU_TRY(launch_conv3x3(c->prec, in, v.wf, training ? P(c, v.p_b) : v.fold_bias, v.y, v.cout, nullptr, 0,
+                        training ? c->stats : nullptr, &nt, B, H, W, s));
   const int64_t off = c->bns[v.bn].off;
   if (training)
     FU_TRY(launch_bn_finalize(c->stats, nt, v.cout, (int64_t)B * H * W, P(c, v.p_b), P(c, v.p_g), P(c, v.p_beta),
                               BN_EPS, BN_MOMENTUM, v.mean, v.invstd, v.a, v.b, c->RM + off, c->RV + off,
                               c->NBT + v.bn, c->dscratch, s));
-  else
-    FU_TRY(launch_bn_eval_coeffs(v.cout, P(c, v.p_g), P(c, v.p_beta), c->RM + off, c->RV + off, BN_EPS, v.a, v.b, s));
   return 0;
 }
 
@@ -762,7 +803,7 @@ int fuse_backward(fu_ctx* c, int B, hipStream_t s) {
 int forward_impl(fu_ctx* c, const float* x, const SrcList* srcs, int B, bool training, float* logits_out,
                  hipStream_t s) {
   const fu_config& f = c->cfg;
-  if (c->packed_dirty) FU_TRY(repack(c, s));
+  if (c->packed_dirty || c->packed_eval != !training) FU_TRY(repack(c, s, !training));
   for (int e = 0; e < c->nE; ++e) {
     if (srcs)     // several input tensors side by side (fu_forward_srcs): the concat happens inside the layout conversion
       FU_TRY(launch_gather_nchw_to_nhwc(c->prec, *srcs, c->xin[e], B, c->enc_ch[e], f.height, f.width, c->cin_pad0[e],
@@ -839,7 +880,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   v.pool_g = nullptr;
   v.bnb_tiles = 0;
   // weight (and bias) gradient
-  const ConvIn in = conv_input(c, i, j);
+  ConvIn in = conv_input(c, i, j);
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
   hipStream_t ws = s;
   if (side) {
@@ -847,7 +888,7 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     FU_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_gy, 0));
     ws = c->side;
   }
-  prof_arm(c, FU_K_WGRAD, fl);
+  in.opt.prof = prof_arm(c, FU_K_WGRAD, fl);
   FU_TRY(launch_conv3x3_wgrad(c->prec, in, v.gy, v.cout, c->slab, G(c, v.p_w), v.cin_real, dbp, ndb,
                               G(c, v.p_b), B, H, W, ws));
   if (side) {
@@ -856,41 +897,33 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
     c->wg_parity ^= 1;
   }
   // data gradient
-  if (!(K.role == 0 && j == 0)) prof_arm(c, FU_K_CONV3X3, fl);
+  ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
+  if (!(K.role == 0 && j == 0)) din.opt.prof = prof_arm(c, FU_K_CONV3X3, fl);
   if (j == 1) {
     // this dgrad's destination is dL/d relu(bn(y)) of the block's first conv: a kernel that can (the row-stationary 16-bit
     // one) also leaves that BatchNorm's backward sums in bnb_part, consumed by the very next launch_bn_bwd on this stream
     Conv& v0 = K.c[0];
     const bool separate = g_bnb_separate != 0;      // testing hook / FU_BNB_SEPARATE: always the separate reduce pass
     int tiles = 0;
+    BnbFuse f;
     if (c->prec != PREC_F32 && !c->sync.hook && !separate) {
-      BnbFuse f;
       f.y = v0.y; f.a = v0.a; f.b = v0.b; f.mean = v0.mean; f.invstd = v0.invstd;
       f.part = c->bnb_part; f.max_elems = c->bnb_cap; f.tiles_out = &tiles;
-      g_bnb_fuse = f;
+      din.opt.bnb = &f;
     }
-    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
-    const int st = launch_conv3x3(c->prec, din, v.wd, nullptr, v0.gy, v0.cout, nullptr, 0, nullptr, nullptr, B, H, W, s);
-    g_bnb_fuse = BnbFuse();
-    if (st) return st;
+    FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, v0.gy, v0.cout, nullptr, 0, nullptr, nullptr, B, H, W, s));
     v0.bnb_tiles = tiles;
     FU_TRY(perturb_bnb(c->bnb_part, tiles, v0.cout, s));
   } else if (K.kind == BK_DOWN) {
-    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, K.g_pooled, v.cin_real, nullptr, 0, nullptr, nullptr, B, H, W,
                           s));
     // the pool's backward (route g_pooled to the first argmax of every window, add to the skip gradient) is folded into
     // the BN backward of the pooled tensor: the next backward block on this stream (k_bn_bwd_pool)
     Conv& pv = c->blk[i - 1].c[1];
-    if (getenv("FU_POOL_BWD_SEPARATE"))
-      FU_TRY(launch_maxpool2_bwd(c->prec, K.g_pooled, pv.y, pv.a, pv.b, pv.gy, B, c->Hs[pv.level], c->Ws[pv.level],
-                                 pv.cout, s));
-    else
-      pv.pool_g = K.g_pooled;
+    pv.pool_g = K.g_pooled;
   } else if (K.kind == BK_UP) {
     const Feat sk = level_feat(c, K.skip);
     const Feat pv = low_feat(c, i);
-    ConvIn din{v.gy, v.cout, nullptr, nullptr, nullptr, 0};
     FU_TRY(launch_conv3x3(c->prec, din, v.wd, nullptr, sk.gy, sk.C, K.g_up, v.cin_real - sk.C, nullptr, nullptr,
                           B, H, W, s));
     const int h = c->Hs[K.level + 1], w = c->Ws[K.level + 1];
@@ -1558,11 +1591,9 @@ int fu_op_conv3x3_dgrad_bnsums(int precision, const void* dy, int Cout, const fl
   BnbFuse f;
   f.y = y; f.a = bn_a; f.b = bn_b; f.mean = mean; f.invstd = invstd;
   f.part = (float*)part.p; f.max_elems = cap; f.tiles_out = &tiles;
-  g_bnb_fuse = f;
   ConvIn in{dy, Cout, nullptr, nullptr, nullptr, 0};
-  const int st = launch_conv3x3(p, in, wd.p, nullptr, dx, C0, nullptr, 0, nullptr, nullptr, B, H, W, s);
-  g_bnb_fuse = BnbFuse();
-  if (st) return st;
+  in.opt.bnb = &f;
+  FU_TRY(launch_conv3x3(p, in, wd.p, nullptr, dx, C0, nullptr, 0, nullptr, nullptr, B, H, W, s));
   if (tiles <= 0) {
     set_error("fu_op_conv3x3_dgrad_bnsums: the kernel that ran does not emit the sums for this shape / dispatch");
     return FU_ERR_UNSUPPORTED;

@@ -188,10 +188,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 #endif  // __HIPCC__
 
-// Optional event pair recorded immediately around the main kernel of the next conv / wgrad launch
-// (set by the API layer when profiling is on, cleared by the launcher).
+// Optional event pair recorded immediately around the main kernel of ONE conv / wgrad launch (LaunchOpts::prof: filled by
+// the API layer from the context's profiler when profiling is on; per launch, never process-wide state).
 struct ProfSlot { hipEvent_t start = nullptr; hipEvent_t stop = nullptr; };
-extern thread_local ProfSlot g_prof_slot;
 
 // Exact data-parallel mode (fu_set_exact_sync): at every statistics reduction the partial sums are summed over the
 // ranks before they are finalised.  The API layer points g_sync at the context's descriptor for the duration of a
@@ -218,7 +217,7 @@ extern thread_local const float* g_grad_unscale;
 // BatchNorm-backward sums from the PRODUCER of dL/dz (round 2): a dgrad launch whose single destination g = dL/d relu(bn(y))
 // feeds a BatchNorm backward can emit that backward's two sums (sum g*m, sum g*m*xhat, m = [a*y + b > 0]) per workgroup
 // tile from its epilogue, where g is still in registers -- k_bn_bwd_reduce (one read of g and one of y, 14 launches per
-// step) then disappears for that layer.  The API layer fills this request right before launch_conv3x3 and clears it after;
+// step) then disappears for that layer.  The API layer passes this request with the launch (ConvIn::opt.bnb);
 // a kernel that honours it (the row-stationary 16-bit kernel, single destination, <= max_tiles workgroup tiles) writes
 // part[tile][channel][2] and *tiles_out = number of tiles; everything else leaves *tiles_out untouched (0 = not fused).
 struct BnbFuse {
@@ -228,10 +227,28 @@ struct BnbFuse {
   int64_t max_elems = 0;                   // capacity of part (floats)
   int* tiles_out = nullptr;
 };
-extern thread_local BnbFuse g_bnb_fuse;
+// per-launch options of the conv / wgrad launchers (host side only; travels inside ConvIn)
+struct LaunchOpts {
+  ProfSlot prof;                  // events around the main kernel
+  const BnbFuse* bnb = nullptr;   // dgrad launches: request for the destination BatchNorm's backward sums
+};
 // out = dlogits * (*up_scale_dev or 1) * (S or 1); scale != null (fp16): S chosen from max|dlogits * up| and written to scale[0..1]
 int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const float* up_scale_dev,
                          float* partials /* >= 256 floats */, float* scale /* [2] or null */, hipStream_t s);
+
+#ifdef FU_EXPERIMENTS   // ablation-by-skip in variant builds only (tools/build_variant.sh exp -DFU_EXPERIMENTS): FU_EXP_SKIP bit mask,
+// 1 = BN forward finalize, 2 = BN backward finalize, 4 = wgrad slab reduce + transpose, 8 = weight pack, 16 = BN backward apply,
+// 32 = bilinear backward, 64 = pool-folded BN backward passes.  The results are WRONG; only the step time means something.
+#include <stdlib.h>
+static inline int exp_skip() {
+  static int m = -1;
+  if (m < 0) { const char* e = getenv("FU_EXP_SKIP"); m = e ? atoi(e) : 0; }
+  return m;
+}
+#define FU_EXP_SKIP(bit) (::fu::exp_skip() & (bit))
+#else
+#define FU_EXP_SKIP(bit) 0
+#endif
 
 // ---- kernel launchers (implemented in the .hip files) ----------------------------------------
 // All pointers are device pointers; T-typed buffers are `void*` + Prec.
@@ -242,6 +259,7 @@ struct ConvIn {              // the (virtual) input of a 3x3 convolution
   const float* b0;
   const void* src1; int C1;  // next C1 channels, taken as they are (may be null/0)
   bool center_only = false;  // the packed weights are a 1x1 conv embedded as the centre tap (late-fusion convs)
+  LaunchOpts opt;            // events / fused-sum request of this launch
 };
 
 // conv as implicit GEMM: out[p][n] = sum_{tap,c} in[p+tap][c] * wpk[tap][c][n] (+bias[n])
@@ -311,9 +329,6 @@ int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, 
                        hipStream_t s);
 // fp64 scratch needed by the two-level reductions: elements for a layer with C channels
 static inline int64_t reduce_scratch_elems(int C) { return (int64_t)32 * C * 2; }
-// eval: a,b from the running statistics
-int launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
-                          const float* running_var, float eps, float* a, float* b, hipStream_t s);
 // backward: g (in place -> dy).  Two launches + finalize inside.  partials scratch: >= bn_bwd_partial_elems.
 int64_t bn_bwd_partial_elems(int C, int64_t npix);
 // g_pool != null: y's 2x2 max-pool ran in forward and g_pool [B, H/2, W/2, C] is dL/d(pooled): the pool's backward is folded
@@ -325,10 +340,6 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
 
 int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                     hipStream_t s);
-// g_src[argmax] += g_dst
-int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const float* a, const float* b, void* g_src,
-                        int B, int H, int W, int C, hipStream_t s);
-
 struct UpTables {  // device tables for one bilinear x2 resize (H x W -> 2H x 2W, placed inside outH x outW)
   const int* y_i0; const int* y_i1; const float* y_w1;  // [2H]
   const int* x_i0; const int* x_i1; const float* x_w1;  // [2W]
@@ -349,7 +360,6 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
 int launch_depth_to_space(Prec p, const void* y4, void* up, int B, int h, int w, int C, int outH, int outW, hipStream_t s);
 int launch_space_to_depth(Prec p, const void* gup, void* g4, int B, int h, int w, int C, int outH, int outW, hipStream_t s);
 int launch_colsum_partials(const float* partials, int n, int C, float* out, hipStream_t s);
-int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, int outW, hipStream_t s);
 int launch_channel_partial_sums(Prec p, const void* g, int C, int64_t npix, float* partials, int* n_partials,
                                 hipStream_t s);
 int launch_convT_to_w3(const float* w, const float* b, int Cin, int Cout, float* w3, float* bias4, hipStream_t s);

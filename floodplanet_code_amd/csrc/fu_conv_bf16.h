@@ -137,10 +137,10 @@ struct BConvP {
 
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
 bool conv3x3_bf16_fast_eligible(const BConvP& P);
-int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s);
+int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s);
 // row-stationary 16x16x32 kernel (fu_conv_rs.hip)
 bool conv3x3_rs_eligible(const BConvP& P);
-int launch_conv3x3_rs(BConvP& P, hipStream_t s);
+int launch_conv3x3_rs(BConvP& P, const LaunchOpts& o, hipStream_t s);
 
 }  // namespace fu
 

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_bf16(BConvP P) {
 int conv3x3_num_stat_tiles_bf16(int B, int H, int W) { return B * ceil_div(H, 16) * ceil_div(W, 16); }
 
 template <int WM, int WN, int NTW>
-static int launch_cfg(BConvP& P, hipStream_t s) {
+static int launch_cfg(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   using Cfg = BCfg<WM, WN, NTW>;
   P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
@@ -353,8 +353,7 @@ static int launch_cfg(BConvP& P, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   hipLaunchKernelGGL((k_conv3x3_bf16<WM, WN, NTW>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
@@ -394,7 +393,7 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   // and a warp-specialised 4 loader + 4 compute wave version with two LDS stages (790-915 TF).  Removing the per-chunk
   // staging altogether lets the same MFMA loop run at 1200-1430 TF, so staging costs ~30 % on the deep layers.)
   if (!g_bf16_force_general && conv3x3_bf16_fast_eligible(P)) {
-    const int st = launch_conv3x3_bf16_fast(P, s);
+    const int st = launch_conv3x3_bf16_fast(P, in.opt, s);
     if (n_stat_tiles) *n_stat_tiles = P.nPix;
     return st;
   }
@@ -404,8 +403,8 @@ int launch_conv3x3_bf16(const ConvIn& in, const bf16_t* wpk, const float* bias, 
   else cfg = 2;
   if (g_bf16_force_cfg == 0 || g_bf16_force_cfg == 2) cfg = g_bf16_force_cfg;
   int st;
-  if (cfg == 0) st = launch_cfg<4, 1, 2>(P, s);
-  else st = launch_cfg<4, 1, 1>(P, s);
+  if (cfg == 0) st = launch_cfg<4, 1, 2>(P, in.opt, s);
+  else st = launch_cfg<4, 1, 1>(P, in.opt, s);
   if (n_stat_tiles) *n_stat_tiles = P.nPix;
   return st;
 }
@@ -1096,7 +1095,7 @@ int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_rea
                         int ndb, float* db, hipStream_t s, bool ci4);
 
 template <int WMI, int PTH, int TAPS = 9>
-static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
+static int launch_wgrad_cfg(BWgP& P, int target_wgs, const LaunchOpts& o, hipStream_t s) {
   using Cfg = WCfg<WMI, PTH>;
   P.tilesX = ceil_div(P.W, Cfg::PTW); P.tilesY = ceil_div(P.H, PTH);
   P.nPix = P.B * P.tilesX * P.tilesY;
@@ -1113,8 +1112,7 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   hipLaunchKernelGGL((k_wgrad_bf16<WMI, PTH, TAPS>), dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
@@ -1129,7 +1127,7 @@ static int launch_wgrad_cfg(BWgP& P, int target_wgs, hipStream_t s) {
 int g_wgrad_force_lockstep = FU_WGRAD_LOCKSTEP_DEFAULT;   // testing hook (fu_test_force_lockstep_wgrad): 1 = k_wgrad_bf16<4,8> instead of the ping-pong kernel, 2 = the ping-pong kernel with its general staging
 #endif
 
-static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
+static int launch_wgrad_pp(BWgP& P, int target_wgs, const LaunchOpts& o, hipStream_t s) {
   using Cfg = WPCfg;
   P.tilesX = ceil_div(P.W, Cfg::PTW); P.tilesY = ceil_div(P.H, Cfg::PTH);
   P.nPix = P.B * P.tilesX * P.tilesY;
@@ -1155,8 +1153,7 @@ static int launch_wgrad_pp(BWgP& P, int target_wgs, hipStream_t s) {
   const bool fast = g_wgrad_force_lockstep != 2 && P.H % Cfg::PTH == 0 && P.W % Cfg::PTW == 0 && P.Cin % Cfg::CI_T == 0 &&
                     P.Cout % Cfg::CO_T == 0 && npx < (1 << 24) && npx * cmax * 2 < (int64_t(1) << 32) &&
                     npx * P.Cout * 2 < (int64_t(1) << 32) && (int64_t)P.nPix * nT < (int64_t(1) << 31);
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   if (fast) hipLaunchKernelGGL(k_wgrad_bf16_pp<true>, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   else hipLaunchKernelGGL(k_wgrad_bf16_pp<false>, dim3(nT * P.S), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
@@ -1197,15 +1194,15 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   int st;
   // embedded 1x1 (late-fusion convs): the stage is all staging, so the lock-step kernel (all 8 waves stage together) wins
   // over the ping-pong one; the eight unwritten tap slabs reach only taps of dw_oihw that the caller never reads
-  if (in.center_only && !g_bf16_force_full_taps && P.Cin > 64) st = launch_wgrad_cfg<4, 8, 1>(P, 256, s);
-  else if (in.center_only && !g_bf16_force_full_taps) st = launch_wgrad_cfg<2, 8, 1>(P, 512, s);
+  if (in.center_only && !g_bf16_force_full_taps && P.Cin > 64) st = launch_wgrad_cfg<4, 8, 1>(P, 256, in.opt, s);
+  else if (in.center_only && !g_bf16_force_full_taps) st = launch_wgrad_cfg<2, 8, 1>(P, 512, in.opt, s);
 #ifdef FU_EXPERIMENTS   // A/B knob (tools/ab_*.sh): FU_WGRAD_MODE=1 the 256-thread 64 x 64 kernel everywhere (512 WGs), 2 = the same at 256 WGs
-  else if (wgrad_mode_env() == 1) st = launch_wgrad_cfg<2, 8>(P, 512, s);
-  else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, s);
+  else if (wgrad_mode_env() == 1) st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);
+  else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, in.opt, s);
 #endif
-  else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, 256, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
-  else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, s);
-  else st = launch_wgrad_cfg<2, 8>(P, 512, s);              // 256 threads, 64 x 64, two WGs per CU
+  else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, 256, in.opt, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, in.opt, s);
+  else st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);              // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;
   return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s, true);
 }

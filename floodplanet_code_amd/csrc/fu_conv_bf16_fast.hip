@@ -540,7 +540,7 @@ bool conv3x3_bf16_fast_eligible(const BConvP& P) {
 }
 
 template <int NTW, int TAPS = 9, int MT = 2, int KCH = 32>
-static int launch_fast_cfg(BConvP& P, hipStream_t s) {
+static int launch_fast_cfg(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   using Cfg = FCfg<NTW, TAPS, MT, KCH>;
   P.tilesX = ceil_div(P.W, Cfg::TW); P.tilesY = ceil_div(P.H, Cfg::TH);
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, Cfg::BN);
@@ -553,8 +553,7 @@ static int launch_fast_cfg(BConvP& P, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   hipLaunchKernelGGL((k_conv3x3_bf16_fast<NTW, TAPS, MT, KCH>), dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s,
                      P);
@@ -565,17 +564,17 @@ static int launch_fast_cfg(BConvP& P, hipStream_t s) {
 
 // Tile choice (all tiles are 16x16 = 256 output pixels): 64 output channels per workgroup when that still yields
 // >= 512 workgroups (two per CU), else 32.
-int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
+int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
   const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
-  if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, s) : launch_fast_cfg<1, 1>(P, s);
+  if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, o, s) : launch_fast_cfg<1, 1>(P, o, s);
   // Row-stationary kernel (fu_conv_rs.hip), wherever the shape is eligible and one of its tiles gives every CU two
   // workgroups.  Measured per layer against the kernels below (bench shapes, forward, tools/conv_modes.py): 5-11 % faster
   // on the 128x128, 64x64 and 32x32 layers with N >= 512 channels x tiles, equal on the two-chunk 256x256 layers, slower
   // below 512 workgroups (16x16 level, 512 -> 256 at 32x32).  Tile mode 3 forces it, modes 1 / 2 exclude it.
   if (conv3x3_rs_eligible(P)) {
     const int64_t t256 = (int64_t)P.B * (P.H / 16) * (P.W / 16) * (P.N / 64);
-    if (g_bf16_tile_mode == 3 || (g_bf16_tile_mode == 0 && t256 >= 512)) return launch_conv3x3_rs(P, s);
+    if (g_bf16_tile_mode == 3 || (g_bf16_tile_mode == 0 && t256 >= 512)) return launch_conv3x3_rs(P, o, s);
   }
   // tall tile (16 x 32 pixels, 16-channel chunks).  Measured per layer against the square tile (bench shapes, one
   // stream): 5-9 % faster where it still yields >= 2048 workgroups (the 256x256 layers; the 8-channel first conv 60 ->
@@ -583,8 +582,8 @@ int launch_conv3x3_bf16_fast(BConvP& P, hipStream_t s) {
   const int64_t t512 = (int64_t)P.B * ceil_div(P.H, 32) * ceil_div(P.W, 16);
   const bool tall = g_bf16_tile_mode == 2 ? wide
                                           : (g_bf16_tile_mode == 0 && wide && t512 * ceil_div(P.N, 64) >= 2048);
-  if (tall) return launch_fast_cfg<2, 9, 4, 16>(P, s);
-  return wide ? launch_fast_cfg<2>(P, s) : launch_fast_cfg<1>(P, s);
+  if (tall) return launch_fast_cfg<2, 9, 4, 16>(P, o, s);
+  return wide ? launch_fast_cfg<2>(P, o, s) : launch_fast_cfg<1>(P, o, s);
 }
 
 }  // namespace fu

@@ -265,8 +265,7 @@ int launch_conv3x3_f32(const ConvIn& in, const float* wpk, const float* bias, fl
   P.tilesX = ceil_div(W, 16); P.tilesY = ceil_div(H, th); P.nPix = B * P.tilesX * P.tilesY; P.nCo = ceil_div(P.N, 64);
   const int grid = P.nPix * P.nCo;
   if (n_stat_tiles) *n_stat_tiles = P.nPix;
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = in.opt.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   if (th == 8) {
     const size_t sh = ConvCfg<8>::SMEM_FLOATS * sizeof(float);
@@ -531,6 +530,7 @@ static int launch_wgrad_reduce_sl(const float* slab, int S, int Cin, int Cout, i
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
                         int ndb, float* db, hipStream_t s, bool ci4) {
   FU_REQUIRE(!ci4 || Cin % 4 == 0, "wgrad_reduce: the interleaved slab layout needs c_in %% 4 == 0");
+  if (FU_EXP_SKIP(4)) return 0;
   int st;
   if (S >= 64) st = launch_wgrad_reduce_sl<16>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
   else if (S >= 16) st = launch_wgrad_reduce_sl<4>(slab, S, Cin, Cout, cin_real, dw, dbp, ndb, db, s);
@@ -575,8 +575,7 @@ int launch_conv3x3_wgrad_f32(const ConvIn& in, const float* dy, int Cout, float*
   P.nCi = ceil_div(P.Cin, WG_CT); P.nCo = ceil_div(Cout, WG_CT);
   const int grid = P.nCi * P.nCo * P.S;
   const size_t sh = (size_t)(WG_NHP * WG_CT + 64 * WG_CT) * sizeof(float);
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = in.opt.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   hipLaunchKernelGGL(k_wgrad_f32, dim3(grid), dim3(256), sh, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);

@@ -491,7 +491,7 @@ bool conv3x3_rs_eligible(const BConvP& P) {
 }
 
 template <int ROWS_>
-static int launch_rs_cfg(BConvP& P, hipStream_t s) {
+static int launch_rs_cfg(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   using Cfg = RCfg<ROWS_>;
   P.tilesX = P.W / Cfg::TW; P.tilesY = P.H / Cfg::TH;
   P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = P.N / Cfg::BN;
@@ -505,8 +505,7 @@ static int launch_rs_cfg(BConvP& P, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
     attr_set = true;
   }
-  const ProfSlot ps = g_prof_slot;
-  g_prof_slot = ProfSlot();
+  const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
   hipLaunchKernelGGL(k_conv3x3_bf16_rs<ROWS_>, dim3(P.nPix * P.nCo), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
@@ -515,11 +514,12 @@ static int launch_rs_cfg(BConvP& P, hipStream_t s) {
 }
 
 // 16 x 32-pixel tiles where they still give every CU two workgroups, 16 x 16 otherwise
-int launch_conv3x3_rs(BConvP& P, hipStream_t s) {
+int launch_conv3x3_rs(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   const int64_t t512 = (int64_t)P.B * (P.H / 32) * (P.W / 16) * (P.N / 64);
   const bool tall = (P.H % 32) == 0 && t512 >= 512;
   // BatchNorm-backward sums of the destination, if the API layer asked for them and this launch can give them
-  const BnbFuse& f = g_bnb_fuse;
+  static const BnbFuse none;
+  const BnbFuse& f = o.bnb ? *o.bnb : none;
   if (f.y != nullptr && f.tiles_out != nullptr && P.a0 == nullptr && P.dst1 == nullptr && P.stats == nullptr) {
     const int64_t tiles = (int64_t)P.B * (P.H / (tall ? 32 : 16)) * (P.W / 16);
     if (tiles * P.N * 2 <= f.max_elems) {
@@ -528,8 +528,8 @@ int launch_conv3x3_rs(BConvP& P, hipStream_t s) {
       *f.tiles_out = (int)tiles;
     }
   }
-  if (tall) return launch_rs_cfg<8>(P, s);
-  return launch_rs_cfg<4>(P, s);
+  if (tall) return launch_rs_cfg<8>(P, o, s);
+  return launch_rs_cfg<4>(P, o, s);
 }
 
 }  // namespace fu

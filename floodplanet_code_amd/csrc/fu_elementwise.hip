@@ -10,7 +10,6 @@ namespace fu {
 
 thread_local const SyncDesc* g_sync = nullptr;
 thread_local const float* g_grad_unscale = nullptr;
-thread_local BnbFuse g_bnb_fuse;
 
 int sync_sum_over_ranks(void* payload, int64_t n_elems, bool is_double, hipStream_t s) {
   const SyncDesc* d = g_sync;
@@ -38,7 +37,6 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const char* get_error() { return g_err; }
-thread_local ProfSlot g_prof_slot;
 
 #define FU_LAUNCH_CHECK()                                                       \
   do {                                                                          \
@@ -370,6 +368,7 @@ int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, 
                        const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
                        float* a, float* b, float* running_mean, float* running_var, int64_t* nbt, double* dscratch,
                        hipStream_t s) {
+  if (FU_EXP_SKIP(1)) return 0;
   if (sync_world() <= 1 && C % 4 == 0) {
     BnFwdOut o{conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt};
     hipLaunchKernelGGL((k_bn_stats_fused<0, BnFwdOut>), dim3(C / 4), dim3(256), 0, s, partials, nTiles, C, (double)count, o);
@@ -382,25 +381,6 @@ int launch_bn_finalize(const float* partials, int nTiles, int C, int64_t count, 
   hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(C, 8)), dim3(256), 0, s, dscratch, G, C,
                      (double)count * sync_world(),
                      conv_bias, gamma, beta, eps, momentum, mean, invstd, a, b, running_mean, running_var, nbt);
-  FU_LAUNCH_CHECK();
-  return 0;
-}
-
-__global__ void k_bn_eval_coeffs(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                 float* __restrict__ a, float* __restrict__ b) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
-  const float aa = gamma[c] * invstd;
-  a[c] = aa;
-  b[c] = beta[c] - rm[c] * aa;
-}
-
-int launch_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
-                          const float* running_var, float eps, float* a, float* b, hipStream_t s) {
-  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ceil_div(C, 64)), dim3(64), 0, s, C, gamma, beta, running_mean,
-                     running_var, eps, a, b);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -672,7 +652,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
   const int rows = BNB_THREADS / (C >> 2);
   const size_t sh1 = (size_t)rows * C * 2 * sizeof(float);
   const bool pool = g_pool != nullptr;     // the max-pool backward of this tensor is folded into the two passes
-  if (pool) {
+  if (pool && FU_EXP_SKIP(64)) {
+  } else if (pool) {
     FU_REQUIRE((int64_t)B * H * W == npix && BNB_THREADS % (C >> 2) == 0, "bn_bwd (pooled): bad geometry");
     // both fast_div decodes of k_bn_bwd_pool need n * d < 2^32: windows / Ww and (windows / Ww) / Hw
     FU_REQUIRE(npix < ((int64_t)1 << 31) && (int64_t)B * ((H + 1) / 2) * (int64_t)((W + 1) / 2) * ((W + 1) / 2) < ((int64_t)1 << 32) &&
@@ -693,7 +674,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     hipLaunchKernelGGL(k_bn_bwd_reduce<f16_t>, dim3(nb), dim3(BNB_THREADS), sh1, s, (const f16_t*)g,
                        (const f16_t*)y, C, npix, a, b, mean, invstd, partials);
   FU_LAUNCH_CHECK();
-  if (sync_world() <= 1) {
+  if (FU_EXP_SKIP(2)) {
+  } else if (sync_world() <= 1) {
     BnBwdOut o{g_grad_unscale, dgamma, dbeta, coef};
     hipLaunchKernelGGL((k_bn_stats_fused<1, BnBwdOut>), dim3(C / 4), dim3(256), 0, s, partials,
                        ext_partials > 0 ? ext_partials : nb, C, (double)npix, o);
@@ -707,7 +689,8 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     FU_LAUNCH_CHECK();
   }
   const size_t sh2 = (size_t)rows * C * sizeof(float);
-  if (pool) {
+  if ((pool && FU_EXP_SKIP(64)) || (!pool && FU_EXP_SKIP(16))) {
+  } else if (pool) {
     if (p == PREC_F32) launch_bn_bwd_pool_t<float>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
     else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
     else launch_bn_bwd_pool_t<f16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
@@ -784,45 +767,6 @@ __global__ __launch_bounds__(256) void k_maxpool2(const T* __restrict__ src, con
 }
 
 // g_src[first argmax of the window] += g_dst   (ties -> first in row-major order, as ATen's max_pool2d)
-template <typename T>
-__global__ __launch_bounds__(256) void k_maxpool2_bwd(const T* __restrict__ gdst, const T* __restrict__ ysrc,
-                                                      const float* __restrict__ a, const float* __restrict__ b,
-                                                      T* __restrict__ gsrc, int H, int W, int C, int Ho, int Wo, int CV,
-                                                      unsigned rcpCV) {
-  constexpr int V = VecIO<T>::V;
-  const int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= Wo * CV) return;
-  const int ox = fast_div(item, CV, rcpCV), cv = item - ox * CV;
-  const int oy = blockIdx.y, bb = blockIdx.z;
-  float av[V], bv[V];
-  const bool bn = a != nullptr;
-  if (bn) load_coef<V>(a, b, cv * V, av, bv);
-  const size_t off = ((size_t)(bb * H + oy * 2) * W + ox * 2) * C + cv * V;
-  const size_t offs[4] = {off, off + C, off + (size_t)W * C, off + (size_t)W * C + C};
-  float z[4][V], gv[V];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load_act<T, V>(ysrc + offs[q], av, bv, bn, z[q]);
-  VecIO<T>::load(gdst + ((size_t)(bb * Ho + oy) * Wo + ox) * C + cv * V, gv);
-  int arg[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    int am = 0;
-    float m = z[0][j];
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-      if (z[q][j] > m) { m = z[q][j]; am = q; }
-    arg[j] = am;
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float cur[V];
-    VecIO<T>::load(gsrc + offs[q], cur);
-#pragma unroll
-    for (int j = 0; j < V; ++j) cur[j] += (arg[j] == q) ? gv[j] : 0.f;
-    VecIO<T>::store(gsrc + offs[q], cur);
-  }
-}
-
 // launch geometry of the row kernels above
 template <typename T>
 static bool row_grid(int C, int items_w, int rows, int B, dim3* grid, int* CV, unsigned* rcp) {
@@ -855,26 +799,6 @@ int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, voi
   return 0;
 }
 
-int launch_maxpool2_bwd(Prec p, const void* g_dst, const void* y_src, const float* a, const float* b, void* g_src,
-                        int B, int H, int W, int C, hipStream_t s) {
-  const int Ho = H / 2, Wo = W / 2;
-  dim3 g; int CV; unsigned rcp;
-  if (p == PREC_F32) {
-    FU_REQUIRE(row_grid<float>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_maxpool2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (const float*)y_src, a, b,
-                       (float*)g_src, H, W, C, Ho, Wo, CV, rcp);
-  } else if (p == PREC_BF16) {
-    FU_REQUIRE(row_grid<bf16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_maxpool2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (const bf16_t*)y_src, a, b,
-                       (bf16_t*)g_src, H, W, C, Ho, Wo, CV, rcp);
-  } else {
-    FU_REQUIRE(row_grid<f16_t>(C, Wo, Ho, B, &g, &CV, &rcp), "maxpool_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_maxpool2_bwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)g_dst, (const f16_t*)y_src, a, b,
-                       (f16_t*)g_src, H, W, C, Ho, Wo, CV, rcp);
-  }
-  FU_LAUNCH_CHECK();
-  return 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // bilinear x2 (align_corners=True) of relu(a*y+b), zero-padded to outH x outW (F.pad of unet.py:57-62)
@@ -981,6 +905,7 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
 
 int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, int W, int C, int outH, int outW,
                          const UpTables& t, hipStream_t s) {
+  if (FU_EXP_SKIP(32)) return 0;
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
   dim3 g; int CV; unsigned rcp;
   if (p == PREC_F32) {
@@ -1050,24 +975,6 @@ __global__ void k_space_to_depth(const T* __restrict__ gup, T* __restrict__ g4, 
 }
 
 // zero everything outside the [py0, py0+2H) x [px0, px0+2W) window of an outH x outW map (the F.pad region)
-template <typename T>
-__global__ void k_zero_border(T* __restrict__ t, int H2, int W2, int C, int outH, int outW, int py0, int px0,
-                              int64_t total) {
-  const int CV = C >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = idx / CV;
-    const int ox = (int)(r % outW); r /= outW;
-    const int oy = (int)(r % outH);
-    const int uy = oy - py0, ux = ox - px0;
-    if (uy < 0 || uy >= H2 || ux < 0 || ux >= W2) {
-      const float z[4] = {0, 0, 0, 0};
-      ElemIO<T>::store4(t + idx * 4, z);
-    }
-  }
-}
-
-// per-channel partial sums [nblk][C] of an NHWC tensor (bias gradient of the transposed conv)
 template <typename T>
 __global__ void k_channel_partial_sums(const T* __restrict__ g, int C, int64_t npix, float* __restrict__ partials) {
   extern __shared__ float sm[];  // [rows][C]
@@ -1166,23 +1073,6 @@ int launch_space_to_depth(Prec p, const void* gup, void* g4, int B, int h, int w
 }
 int launch_colsum_partials(const float* partials, int n, int C, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_colsum_partials, dim3(ceil_div(C, 64)), dim3(64), 0, s, partials, n, C, g_grad_unscale, out);
-  FU_LAUNCH_CHECK();
-  return 0;
-}
-int launch_zero_border(Prec p, void* t, int B, int H, int W, int C, int outH, int outW, hipStream_t s) {
-  if (outH == 2 * H && outW == 2 * W) return 0;
-  const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
-  const int64_t total = (int64_t)B * outH * outW * (C / 4);
-  const int g = grid_for(total, 256);
-  if (p == PREC_F32)
-    hipLaunchKernelGGL(k_zero_border<float>, dim3(g), dim3(256), 0, s, (float*)t, 2 * H, 2 * W, C, outH, outW, py0, px0,
-                       total);
-  else if (p == PREC_BF16)
-    hipLaunchKernelGGL(k_zero_border<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)t, 2 * H, 2 * W, C, outH, outW, py0,
-                       px0, total);
-  else
-    hipLaunchKernelGGL(k_zero_border<f16_t>, dim3(g), dim3(256), 0, s, (f16_t*)t, 2 * H, 2 * W, C, outH, outW, py0,
-                       px0, total);
   FU_LAUNCH_CHECK();
   return 0;
 }

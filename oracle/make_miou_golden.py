@@ -1,0 +1,73 @@
+"""`mIoU vs ref` reference run (TEST INFRASTRUCTURE; build container only -- it needs no file of /root/reference beyond what
+oracle/make_golden.py already pinned: the oracle IS the reference's arithmetic, bit for bit).
+
+The oracle (torch-CPU fp32 restatement of st_water_seg/models/unet.py + water_seg_model.py:98-108,198-205) trains the
+FULL-WIDTH net (base 64, 17.27 M parameters) on 32 seeded 8-band 128x128 tiles of a task that has to be learnt
+(unet_oracle.make_task_tiles), batch 8, 100 Adam steps (lr 1e-3, 25 passes over the 4 batches in order), then predicts 16
+HELD-OUT tiles in eval mode (BatchNorm running statistics, water_seg_model.py:138-158).  Stored: the micro Jaccard index
+over argmax with ignore_index (water_seg_model.py:46-63, 207-214) on the held-out and on the training tiles, the loss
+curve, and statistics of the held-out eval logits.  tests/test_gpu_unet.py trains the HIP path (fp32 / bf16 / fp16) from
+the same state on the same tiles and bounds the gaps; bench.py reports the same workload as `miou_vs_ref`.
+
+usage: python oracle/make_miou_golden.py        (about 5 minutes on 8 cores)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import unet_oracle as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "miou_golden.json")
+CFG = dict(channels=8, size=128, base=64, n_train=32, n_heldout=16, batch=8, steps=100, lr=1e-3, ignore_index=0,
+           param_seed=5, train_seed=21, heldout_seed=22, signal=0.07)
+
+
+def jaccard(pred, target, ii):
+    m = O.confusion_counts(pred, target, 3, ii)
+    return float(O.metrics_from_counts(m, ii)["MulticlassJaccardIndex"])
+
+
+def main():
+    c = CFG
+    torch.set_num_threads(os.cpu_count() or 1)
+    st = O.make_state(c["channels"], 3, c["base"], True, seed=c["param_seed"], nontrivial_bn=False)
+    train = O.make_task_tiles(c["n_train"], c["channels"], c["size"], c["train_seed"], c["signal"])
+    held = O.make_task_tiles(c["n_heldout"], c["channels"], c["size"], c["heldout_seed"], c["signal"])
+    opt = O.new_adam_state(st)
+    nb = c["n_train"] // c["batch"]
+    losses = []
+    t0 = time.time()
+    for step in range(c["steps"]):
+        k = step % nb
+        b = {"image": train["image"][k * c["batch"]:(k + 1) * c["batch"]], "target": train["target"][k * c["batch"]:(k + 1) * c["batch"]]}
+        _, loss, _ = O.train_step(st, opt, b, c["ignore_index"], c["lr"])
+        losses.append(float(loss))
+        if step % 10 == 9:
+            print(f"step {step + 1}: loss {losses[-1]:.4f} ({time.time() - t0:.0f} s)", flush=True)
+
+    def predict(tiles):
+        out = []
+        for k in range(0, tiles["image"].shape[0], c["batch"]):
+            out.append(O.eval_forward(st, {"image": tiles["image"][k:k + c["batch"]]}))
+        return torch.cat(out)
+
+    lg_h, lg_t = predict(held), predict(train)
+    res = {"config": c,
+           "jaccard_heldout": jaccard(lg_h.argmax(1), held["target"], c["ignore_index"]),
+           "jaccard_train": jaccard(lg_t.argmax(1), train["target"], c["ignore_index"]),
+           "loss_curve": [round(v, 6) for v in losses],
+           "heldout_logits": {"mean": float(lg_h.mean()), "std": float(lg_h.std()), "absmax": float(lg_h.abs().max()),
+                              "per_class_mean": [float(v) for v in lg_h.mean((0, 2, 3))]},
+           "torch": torch.__version__}
+    json.dump(res, open(OUT, "w"), indent=1)
+    print({k: v for k, v in res.items() if k.startswith("jaccard")}, "->", OUT)
+
+
+if __name__ == "__main__":
+    main()

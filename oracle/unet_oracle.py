@@ -200,6 +200,26 @@ def make_batch(B: int, C: int, H: int, W: int, seed: int = 1, n_label_values: in
     return batch
 
 
+def make_task_tiles(n: int, C: int, S: int, seed: int, signal: float = 0.07) -> Dict[str, torch.Tensor]:
+    """A segmentation task that has to be LEARNT (the `mIoU vs ref` workload, oracle/make_miou_golden.py): n tiles
+    [C, S, S].  Target: smooth blobs over {0, 1, 2}; 0 is the ignore class (conf/config.yaml:26), 1 and 2 have to be told
+    apart.  Image: U[0,1) noise + `signal` * (a fixed +-1 band signature of the pixel's class), the whole tile multiplied by
+    a smooth illumination field in [0.7, 1.3] -- per pixel and band the two classes differ by 2*signal against a noise
+    std of 0.29, so a pixel-wise linear rule reaches ~88 % and spatial context is needed for more.  Closed form in
+    (n, C, S, seed): both sides of a comparison build identical tiles from the seed alone."""
+    b = make_batch(n, C, S, S, seed=seed, n_label_values=3)
+    img, tgt = b["image"].numpy().copy(), b["target"].numpy()
+    sig = np.where(hash_uniform(3 * C, 977, 5).reshape(3, C) < 0.5, -1.0, 1.0).astype(np.float32)
+    sig[0] = 0.0
+    img += np.float32(signal) * np.transpose(sig[tgt], (0, 3, 1, 2))
+    yy, xx = np.meshgrid(np.arange(S, dtype=np.float32), np.arange(S, dtype=np.float32), indexing="ij")
+    ph = hash_uniform(n * 4, seed, 6).reshape(n, 4).astype(np.float32)
+    for k in range(n):
+        gain = 1.0 + 0.3 * np.sin(yy * (0.02 + 0.05 * ph[k, 0]) + 6.28 * ph[k, 1]) * np.cos(xx * (0.02 + 0.05 * ph[k, 2]) + 6.28 * ph[k, 3])
+        img[k] *= gain.astype(np.float32)[None]
+    return {"image": torch.from_numpy(img.astype(np.float32)), "target": torch.from_numpy(tgt)}
+
+
 # --------------------------------------------------------------------------- #
 # forward
 # --------------------------------------------------------------------------- #

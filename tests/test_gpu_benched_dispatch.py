@@ -35,8 +35,12 @@ LOWP = {"bf16": dict(code=_lib.FU_BF16, dt=torch.bfloat16, eps=2.0 ** -8),
         "fp16": dict(code=_lib.FU_F16, dt=torch.float16, eps=2.0 ** -11)}
 # whole-net tolerances against the fp32 reference fixtures: the stated ones of tests/test_gpu_unet.py (LOWP_TOL), plus per
 # tensor: gradient norm within a factor and cosine (tensors of >= 64 elements whose reference norm is not noise)
-NET_TOL = {"bf16": dict(lmax=0.25, lrms=0.05, loss=0.03, agree=0.93, cos_med=0.9, cos_min=0.6, norm=(0.5, 2.0)),
-           "fp16": dict(lmax=0.06, lrms=0.008, loss=0.005, agree=0.99, cos_med=0.95, cos_min=0.8, norm=(0.7, 1.4))}
+NET_TOL = {"bf16": dict(lmax=0.25, lrms=0.05, loss=0.03, agree=0.93, cos_med=0.9, cos_min=0.75, norm=(0.5, 2.0)),
+           "fp16": dict(lmax=0.06, lrms=0.008, loss=0.005, agree=0.99, cos_med=0.97, cos_min=0.95, norm=(0.7, 1.4))}
+# f_full_c8_32 (two 32x32 tiles): the deepest BatchNorms see 2 x 2 x 2 = 8 samples per channel and amplify the bf16 rounding of
+# their inputs the way they amplify fp32 rounding; measured on this fixture, forced dispatch and default
+# dispatch alike: median cosine 0.84, minimum 0.62 (bf16); 0.99 / 0.98 (fp16)
+NET_TOL_SMALL = {"bf16": dict(cos_med=0.78, cos_min=0.5), "fp16": {}}
 
 
 def stream():
@@ -79,7 +83,9 @@ def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced
     meta, z = load_golden(name)
     batch, st = case_inputs(meta)
     ii = meta["resolved_ignore_index"]
-    tol = NET_TOL[prec]
+    tol = dict(NET_TOL[prec])
+    if name == "f_full_c8_32":
+        tol.update(NET_TOL_SMALL[prec])
     net = HipUNet(meta["n_in"], 3, base_channels=meta["base"], precision=prec)
     net.load_state_dict(st)
     net.to(DEV).train()
@@ -120,8 +126,22 @@ def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced
           f"cos median {np.median(cos):.4f} min {worst[0]:.4f} ({worst[1]})")
     assert np.median(cos) >= tol["cos_med"], np.median(cos)
     assert worst[0] >= tol["cos_min"], worst
+    # ... and no worse than the default dispatch (fast / general kernels, separate reduce passes) on the same fixture
+    lib.fu_test_conv_tile_mode(0)
+    net.zero_grad(set_to_none=True)
+    loss_d = net.loss(x, t, ii)
+    loss_d.backward()
+    torch.cuda.synchronize()
+    lib.fu_test_conv_tile_mode(3)
+    cos_d = []
+    for j, (k, p) in enumerate(net.named_parameters()):
+        if not is_dead_bias(k) and p.numel() >= 64 and z["grad_stats1"][j][2] >= 1e-5:
+            a, b = p.grad.cpu().double().reshape(-1), g_ref[k].double().reshape(-1)
+            cos_d.append((a @ b / (a.norm() * b.norm() + 1e-30)).item())
+    print(f"    default dispatch: cos median {np.median(cos_d):.4f} min {min(cos_d):.4f}")
+    assert np.median(cos) >= np.median(cos_d) - 0.03 and worst[0] >= min(cos_d) - 0.1
     # the forced dispatch really took the fused-sum route: with the sums back in their own reduce pass the result differs
-    # (another summation order, g after its rounding) -- but only by rounding: loss identical, last BatchNorm's gradients 1e-4
+    # (another summation order, g after its rounding) -- but only by rounding: loss identical, last BatchNorm's gradients to 4e-4
     lib.fu_test_bnb_separate(1)
     loss2 = net.loss(x, t, ii)
     net.zero_grad(set_to_none=True)
@@ -133,7 +153,8 @@ def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced
     assert not torch.equal(g_sep, g_fused)
     for (k, p, off, n) in net._table:
         if k in ("up4.conv.double_conv.4.weight", "up4.conv.double_conv.4.bias"):
-            assert rel(g_fused[off:off + n], g_sep[off:off + n]) <= 1e-4, k
+            # (measured 2e-5 ... 1.1e-4 over the three fixtures and two precisions; a wrong sum is off by O(1))
+            assert rel(g_fused[off:off + n], g_sep[off:off + n]) <= 4e-4, k
 
 
 # ------------------------------------------------------------------------------------------------------------------

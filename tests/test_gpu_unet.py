@@ -596,16 +596,23 @@ def test_plugin_path_uses_fused_adam_and_keeps_torch_semantics():
     assert torch.equal(m2.model.adam_state()[0], ma.model.adam_state()[0])
 
 
-def test_miou_vs_ref_after_training_hip_and_oracle_side_by_side():
-    """`mIoU vs ref` (BASELINE.json metric): HIP fp32, HIP bf16 and the oracle (the reference's arithmetic)
-    train from the same state on the same seeded tiles; the micro Jaccard (argmax, ignore_index) of their eval-mode
-    predictions must agree: fp32 within 0.02, bf16 within 0.05 of the reference path."""
+def test_miou_vs_ref_full_width_training_heldout_tiles():
+    """`mIoU vs ref` (BASELINE.json metric): the oracle -- the reference's arithmetic -- trained the FULL-WIDTH
+    net for 100 Adam steps on 32 seeded 8-band 128x128 tiles of a task that has to be learnt and scored 16 held-out tiles
+    (tests/golden/miou_golden.json, oracle/make_miou_golden.py).  HIP fp32, bf16 and fp16 train from the same state on the
+    same tiles; the micro Jaccard of their eval-mode predictions on the held-out tiles must match the reference path's:
+    fp32 within 0.005, the 16-bit modes within 0.02.  (The held-out score sits well below 1: an implementation that trains
+    worse -- a wrong gradient, a lossy optimiser, broken running statistics in eval mode -- shows up here.)"""
     import bench
-    r = bench.miou_vs_ref(torch.device(DEV), "bf16")
-    j = r["jaccard"]
-    assert j["oracle_fp32"] > 0.5                    # the task was learnt at all
-    assert abs(r["gap_vs_ref"]["hip_fp32"]) <= 0.02, r
-    assert abs(r["gap_vs_ref"]["hip_bf16"]) <= 0.05, r
+    r = bench.miou_vs_ref(torch.device(DEV), "bf16", precisions=["fp32", "bf16", "fp16"])
+    print(r["jaccard_heldout"], r["jaccard_train"], r["final_train_loss"])
+    ref = r["jaccard_heldout"]["oracle_fp32"]
+    assert 0.6 < ref < 0.97                          # the task was learnt, and not saturated
+    assert abs(r["gap_vs_ref"]["hip_fp32"]) <= 0.005, r
+    assert abs(r["gap_vs_ref"]["hip_bf16"]) <= 0.02, r
+    assert abs(r["gap_vs_ref"]["hip_fp16"]) <= 0.02, r
+    for k in ("hip_fp32", "hip_bf16", "hip_fp16"):
+        assert abs(r["final_train_loss"][k] - r["final_train_loss"]["oracle_fp32"]) <= 0.25 * r["final_train_loss"]["oracle_fp32"], r
 
 
 # ---------------------------------------------------------------------------------------------------
