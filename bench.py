@@ -51,6 +51,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the small HIP-vs-oracle training comparison (miou_vs_ref)")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-forward / stitching side measurement")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("FU_STEP_GRAPH", "0")), choices=[0, 1],
+                    help="1: the whole step is captured into a hipGraph once and replayed (N = 1, C-ABI path); the steps whose "
+                         "conv launches are event-timed for the roofline run eagerly either way; the other mode is "
+                         "measured in a short extra pass and reported as `step_other_mode`")
     ap.add_argument("--no-serial-pass", action="store_true",
                     help="skip the extra un-timed pass that measures the dominant kernel without the side stream")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -258,31 +262,38 @@ def miou_vs_ref(dev, dtype, precisions=None):
     def jac(pred, target):
         return SegmentationMetrics(3, ignore_index=ii)(pred.cpu(), target.cpu())["MulticlassJaccardIndex"].item()
 
-    out, losses = {}, {}
+    out, losses, track = {}, {}, {}
     names = precisions or list(dict.fromkeys(["fp32", PRECISION[dtype]]))
     for name in names:
         net = HipUNet(c["channels"], 3, base_channels=c["base"], precision=name)
         net.load_state_dict(st0)
         net.to(dev).train()
-        last = None
+        last, curve = None, []
         for step in range(c["steps"]):
             k = step % nb
             last = net.train_step(xt[k * bs:(k + 1) * bs], tt[k * bs:(k + 1) * bs], ii)
-            net.adam_step(c["lr"], step + 1)
+            curve.append(last)
+            net.adam_step(c["lr"] if step < c["lr_switch"] else c["lr_late"], step + 1)
         net.eval()
         with torch.no_grad():
             ph = torch.cat([net(xh[k:k + bs]).argmax(1) for k in range(0, xh.shape[0], bs)])
             pt = torch.cat([net(xt[k:k + bs]).argmax(1) for k in range(0, xt.shape[0], bs)])
         out[f"hip_{name}"] = {"heldout": jac(ph, th), "train": jac(pt, tt)}
         losses[f"hip_{name}"] = float(last.item())
+        # the first 40 steps, where two correct implementations still walk the same trajectory: per-step loss ratio to the
+        # reference curve (a systematic error in forward, loss, backward, BatchNorm statistics or Adam shows here at once)
+        r = [float(v.item()) / g for v, g in zip(curve[:40], gold["loss_curve"][:40])]
+        track[f"hip_{name}"] = {"max_abs_dev": round(max(abs(v - 1.0) for v in r), 4),
+                                "mean_abs_dev": round(sum(abs(v - 1.0) for v in r) / len(r), 4)}
     ref_h, ref_t = gold["jaccard_heldout"], gold["jaccard_train"]
-    return {"workload": f"{c['steps']} Adam steps (lr {c['lr']}, batch {bs}) on {c['n_train']} seeded {c['channels']}ch "
+    return {"workload": f"{c['steps']} Adam steps (lr {c['lr']}, {c['lr_late']} from step {c['lr_switch'] + 1}; batch {bs}) on {c['n_train']} seeded {c['channels']}ch "
                         f"{c['size']}x{c['size']} tiles, full width (base {c['base']}), ignore_index {ii}; micro Jaccard of the "
                         f"eval-mode argmax on {c['n_heldout']} held-out tiles (and on the training tiles)",
             "reference": "tests/golden/miou_golden.json (oracle/make_miou_golden.py: the reference's arithmetic, torch-CPU fp32)",
             "jaccard_heldout": {"oracle_fp32": round(ref_h, 4), **{k: round(v["heldout"], 4) for k, v in out.items()}},
             "jaccard_train": {"oracle_fp32": round(ref_t, 4), **{k: round(v["train"], 4) for k, v in out.items()}},
             "final_train_loss": {"oracle_fp32": round(gold["loss_curve"][-1], 5), **{k: round(v, 5) for k, v in losses.items()}},
+            "loss_curve_dev_first_40_steps": track,
             "gap_vs_ref": {k: round(v["heldout"] - ref_h, 4) for k, v in out.items()}}
 
 
@@ -411,7 +422,8 @@ def main():
             net = net.to(dev).train()
         else:
             net = HipUNet(args.channels, 3, bilinear=True, base_channels=64, precision=precision).to(dev).train()
-        trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank, time_waits=world > 1)
+        trainer = DataParallelTrainer(net, lr=1e-4, world_size=world, rank=rank, time_waits=world > 1,
+                                      graph=bool(args.graph) and world == 1)
 
     B, Cc, S = args.batch, args.channels, args.size
     g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -454,9 +466,11 @@ def main():
         if on:
             _lib.check(lib.fu_profile_enable(net._ctx, 1 if sampled == 0 else 2))
             sampled += 1
+            trainer._graph_off = True          # event-timed steps are launched eagerly (a replay records no events)
         loss = trainer.step(x, target, 0)
         if on:
             _lib.check(lib.fu_profile_enable(net._ctx, 0))
+            trainer._graph_off = False
         marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
@@ -521,6 +535,24 @@ def main():
             finally:
                 lib.fu_test_bnb_separate(0)
         _lib.check(lib.fu_set_side_stream(net._ctx, 1))
+    other_mode = None
+    if world == 1 and args.path == "cabi" and args.model == "unet" and not args.no_serial_pass:
+        # the step launched the other way (eager <-> captured hipGraph), 20 steps after 3 of warm-up; not part of `value`
+        was = trainer.graph
+        trainer.graph = not was
+        try:
+            for _ in range(3):
+                trainer.step(x, target, 0)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                trainer.step(x, target, 0)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t1) / 20 * 1e3
+            other_mode = {"mode": "hipGraph replay" if trainer.graph else "eager launches", "ms_per_step": round(ms, 3),
+                          "tiles_per_s": round(B / ms * 1e3, 1)}
+        finally:
+            trainer.graph = was
     if best:
         achieved = best["flops"] / (best["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": best["kernel"], "achieved": round(achieved, 3), "peak": peak,
@@ -585,6 +617,8 @@ def main():
         "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)] if step_ms else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": cfg,
+        "step_launch_mode": "hipGraph replay" if (args.graph and world == 1 and args.path == "cabi") else "eager launches",
+        "step_other_mode": other_mode,
         "loss": round(float(loss.item()), 6),
         "roofline": roof,
     }

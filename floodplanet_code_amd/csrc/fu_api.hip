@@ -1353,6 +1353,23 @@ int fu_adam_step(fu_ctx* c, double lr, double beta1, double beta2, double eps, i
   return FU_OK;
 }
 
+int fu_adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale, float out[7]) {
+  FU_REQUIRE(out && step >= 1, "fu_adam_scalars: bad argument");
+  adam_scalars(lr, beta1, beta2, eps, step, grad_scale, out);
+  return FU_OK;
+}
+
+int fu_adam_step_dev(fu_ctx* c, const float* scalars_dev, fu_stream stream) {
+  FU_REQUIRE(c && c->P && c->G && scalars_dev, "fu_adam_step_dev: parameter / gradient buffers not bound, or null scalars");
+  if (!c->adam_m || !c->adam_v) {
+    set_error("fu_adam_step_dev: no moment buffers bound (fu_bind_adam_state)");
+    return FU_ERR_STATE;
+  }
+  FU_TRY(launch_adam_dev(c->P, c->G, c->adam_m, c->adam_v, c->total_params, scalars_dev, (hipStream_t)stream));
+  c->packed_dirty = true;
+  return FU_OK;
+}
+
 int fu_adam_state(fu_ctx* c, float** exp_avg, float** exp_avg_sq) {
   FU_REQUIRE(c, "null context");
   if (exp_avg) *exp_avg = c->adam_m;

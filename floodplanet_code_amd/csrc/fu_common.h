@@ -403,5 +403,7 @@ int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* 
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                 double eps, int64_t step, double grad_scale, hipStream_t s);
+void adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale, float out[7]);
+int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s);
 
 }  // namespace fu

@@ -1170,6 +1170,16 @@ static int wgrad_mode_env() {
 }
 #endif
 
+static int wgrad_pp_target() {
+#ifdef FU_EXPERIMENTS   // FU_WGRAD_TARGET=n: workgroups of the ping-pong kernel (256 = one per CU)
+  static int t = -1;
+  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 256; }
+  return t;
+#else
+  return 256;
+#endif
+}
+
 // upper bound of the slab size over the two configurations below
 int64_t conv3x3_wgrad_slab_elems_bf16(int Cin, int Cout, int B, int H, int W) {
   const int64_t npix = (int64_t)B * ceil_div(H, 8) * ceil_div(W, 16);
@@ -1200,7 +1210,7 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   else if (wgrad_mode_env() == 1) st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);
   else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, in.opt, s);
 #endif
-  else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, 256, in.opt, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
+  else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, wgrad_pp_target(), in.opt, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
   else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, in.opt, s);
   else st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);              // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;

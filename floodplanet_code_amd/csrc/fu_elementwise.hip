@@ -2029,17 +2029,50 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                double eps, int64_t step, double grad_scale, hipStream_t s) {
-  // scalars are formed in double as torch.optim.Adam forms them in Python, then rounded once to float (the cast ATen
-  // applies to a Python scalar operand of a float tensor op)
+// the seven float scalars of k_adam: formed in double as torch.optim.Adam forms them in Python, then rounded once to float
+// (the cast ATen applies to a Python scalar operand of a float tensor op)
+void adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale, float out[7]) {
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const double step_size = lr / bc1;
   const double bc2_sqrt = sqrt(bc2);
-  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size),
-                     (float)grad_scale);
+  out[0] = (float)(1.0 - beta1); out[1] = (float)beta2; out[2] = (float)(1.0 - beta2); out[3] = (float)bc2_sqrt;
+  out[4] = (float)eps; out[5] = (float)(-step_size); out[6] = (float)grad_scale;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                double eps, int64_t step, double grad_scale, hipStream_t s) {
+  float sc[7];
+  adam_scalars(lr, beta1, beta2, eps, step, grad_scale, sc);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, sc[0], sc[1], sc[2], sc[3],
+                     sc[4], sc[5], sc[6]);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same update with its scalars read from DEVICE memory: a captured (hipGraph) step replays this launch unchanged while
+// the step count -- and with it the bias corrections -- moves on; the caller refreshes the seven floats before each replay.
+__global__ void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                           float* __restrict__ v, int64_t n, const float* __restrict__ sc) {
+#pragma clang fp contract(off)
+  const float w1 = sc[0], beta2 = sc[1], omb2 = sc[2], bc2_sqrt = sc[3], eps = sc[4], neg_step = sc[5], gscale = sc[6];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    const float dm = gi - mi;
+    mi = fmaf(w1, dm, mi);
+    const float vb = vi * beta2;
+    const float og = omb2 * gi;
+    vi = vb + og * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float num = neg_step * mi;
+    p[i] = p[i] + num / denom;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_adam_dev, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, scalars_dev);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -114,7 +114,8 @@ class DataParallelTrainer:
     """fwd + CE + block-wise bwd (+ overlapped all-reduce) + fused Adam on a HipUNet."""
 
     def __init__(self, net, lr: float, world_size: int = 1, rank: int = 0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 group=None, cap_bytes: int = 16 << 20, exact: bool = False, time_waits: bool = False):
+                 group=None, cap_bytes: int = 16 << 20, exact: bool = False, time_waits: bool = False,
+                 graph: bool = False):
         """exact=False: DDP semantics (per-rank BN statistics and 1/N_valid, gradients averaged).
         exact=True: SyncBN statistics and a global N_valid (HipUNet.enable_exact_sync); the ranks together reproduce
         one device with world_size x the batch, gradients are summed (SURVEY.md 8(e) "exact mode")."""
@@ -125,6 +126,14 @@ class DataParallelTrainer:
             net.enable_exact_sync(world_size, group)
         self.step_count = 0
         self.time_waits = time_waits
+        # graph=True (single device): the whole step -- fu_forward, fu_loss_ce, fu_backward with its side-stream fork / join,
+        # fu_adam_step_dev -- is captured once into a hipGraph (torch.cuda.CUDAGraph on the capture stream the C calls are
+        # issued on) and replayed; only the seven Adam scalars, which depend on the step count, are refreshed per step.  The
+        # captured launches are valid for ONE (x, target) pair of device buffers: other tensors are copied into them.
+        self.graph = bool(graph) and world_size <= 1
+        self._graph = None
+        self._gx = self._gt = self._gloss = self._gscal = self._gscal_host = None
+        self._g_ignore = None
         self._reducer: Optional[BucketedReducer] = None
         self._synced = False
 
@@ -147,9 +156,60 @@ class DataParallelTrainer:
         net._mark_dirty()
         self._synced = True
 
+    # ------------------------------------------------------------------ captured step
+    def _adam_scalars_to_device(self, step: int):
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_float * 7)()
+        _lib.check(_lib.load().fu_adam_scalars(float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                               int(step), 1.0, buf))
+        self._gscal_host.copy_(torch.tensor(list(buf), dtype=torch.float32))
+        self._gscal.copy_(self._gscal_host, non_blocking=True)       # ordered on the current stream, ahead of the replay
+
+    def _capture(self, x, target, ignore_index):
+        from . import _lib
+        net, dev = self.net, x.device
+        self._gx, self._gt, self._g_ignore = x, target, int(ignore_index)
+        self._gscal = torch.zeros(7, dtype=torch.float32, device=dev)
+        self._gscal_host = torch.zeros(7, dtype=torch.float32).pin_memory()
+        lib = _lib.load()
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            net._forward_raw(self._gx, True, want_logits=False)
+            self._gloss = net._loss_raw(self._gt, self._g_ignore, dev)
+            net._backward_raw(None, dev)
+            _lib.check(lib.fu_adam_step_dev(net._ctx, self._gscal.data_ptr(), net._stream(dev)))
+        net._generation -= 1          # (the capture enqueued nothing; the bookkeeping of _forward_raw is redone per replay)
+        self._graph = g
+
+    def _graph_step(self, x, target, ignore_index):
+        net = self.net
+        if self._graph is not None and (int(ignore_index) != self._g_ignore or x.shape != self._gx.shape):
+            self._graph = None                                        # another workload: capture again
+        if self._graph is None:
+            if net._ctx is None or net._ctx_key[1:3] != tuple(x.shape[2:]) or net._ctx_key[3] < x.shape[0]:
+                return None                                           # no context for this shape yet: one eager step first
+            self._capture(x.detach().contiguous().float(), target.contiguous().long(), ignore_index)
+        if x.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(x)
+        if target.data_ptr() != self._gt.data_ptr():
+            self._gt.copy_(target)
+        self.step_count += 1
+        self._adam_scalars_to_device(self.step_count)
+        self._graph.replay()
+        net._generation += 1
+        net._eval_dirty = True
+        net.attach_grads()
+        return self._gloss
+
     def step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
         from . import _lib
         net = self.net
+        if self.graph and not _FORCE_BLOCKS and not self.exact and not getattr(self, "_graph_off", False):
+            out = self._graph_step(x, target, ignore_index)
+            if out is not None:
+                return out
         if self.world_size > 1 and not self._synced:
             self._sync_initial_state(x.device)
         net._forward_raw(x, True, want_logits=False)

@@ -182,6 +182,14 @@ int fu_bind_adam_state(fu_ctx* ctx, float* exp_avg, float* exp_avg_sq);
 int fu_adam_step(fu_ctx* ctx, double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                  fu_stream stream);
 int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* the bound pointers (NULL when none) */
+/* The same update for a CAPTURED step (hipGraph): the seven float scalars of the kernel -- which depend on the step count --
+ * are read from device memory, so one captured launch serves every replay.  fu_adam_scalars forms them on the host exactly
+ * as fu_adam_step does (out[7]: 1-beta1, beta2, 1-beta2, sqrt(bias_correction2), eps, -lr/bias_correction1, grad_scale);
+ * the caller copies them to scalars_dev before each replay.  All entry points of the hot path enqueue work only (no
+ * allocation, no synchronisation, events and the side stream fork and re-join inside fu_backward), so a caller may capture
+ * fu_forward + fu_loss_* + fu_backward + fu_adam_step_dev on one stream into a graph and replay it. */
+int fu_adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale, float out[7]);
+int fu_adam_step_dev(fu_ctx* ctx, const float* scalars_dev, fu_stream stream);
 int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
 
 /* ---- exact data-parallel mode (SyncBN statistics + global N_valid) ----------------

@@ -3,7 +3,7 @@ oracle/make_golden.py already pinned: the oracle IS the reference's arithmetic, 
 
 The oracle (torch-CPU fp32 restatement of st_water_seg/models/unet.py + water_seg_model.py:98-108,198-205) trains the
 FULL-WIDTH net (base 64, 17.27 M parameters) on 32 seeded 8-band 128x128 tiles of a task that has to be learnt
-(unet_oracle.make_task_tiles), batch 8, 100 Adam steps (lr 1e-3, 25 passes over the 4 batches in order), then predicts 16
+(unet_oracle.make_task_tiles), batch 8, 100 Adam steps (lr 1e-3, then 2e-4 from step 61; 25 passes over the 4 batches in order), then predicts 16
 HELD-OUT tiles in eval mode (BatchNorm running statistics, water_seg_model.py:138-158).  Stored: the micro Jaccard index
 over argmax with ignore_index (water_seg_model.py:46-63, 207-214) on the held-out and on the training tiles, the loss
 curve, and statistics of the held-out eval logits.  tests/test_gpu_unet.py trains the HIP path (fp32 / bf16 / fp16) from
@@ -24,8 +24,16 @@ sys.path.insert(0, ROOT)
 from oracle import unet_oracle as O  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "miou_golden.json")
-CFG = dict(channels=8, size=128, base=64, n_train=32, n_heldout=16, batch=8, steps=100, lr=1e-3, ignore_index=0,
-           param_seed=5, train_seed=21, heldout_seed=22, signal=0.07)
+# lr: 1e-3 for the first 60 steps, 2e-4 for the last 40.  (With 1e-3 throughout, the last third of the run is a noisy
+# regime -- the loss oscillates by +-10 % from step to step -- in which two correct implementations part chaotically:
+# the HIP fp32 path tracks this curve to 0.3 % for 50 steps and then ends 0.015 away in Jaccard, tools/miou_diag.py.  The
+# smaller final rate lets every run settle before it is scored.)
+CFG = dict(channels=8, size=128, base=64, n_train=32, n_heldout=16, batch=8, steps=100, lr=1e-3, lr_late=2e-4,
+           lr_switch=60, ignore_index=0, param_seed=5, train_seed=21, heldout_seed=22, signal=0.07)
+
+
+def lr_at(c, step):          # step: 0-based
+    return c["lr"] if step < c["lr_switch"] else c["lr_late"]
 
 
 def jaccard(pred, target, ii):
@@ -46,7 +54,7 @@ def main():
     for step in range(c["steps"]):
         k = step % nb
         b = {"image": train["image"][k * c["batch"]:(k + 1) * c["batch"]], "target": train["target"][k * c["batch"]:(k + 1) * c["batch"]]}
-        _, loss, _ = O.train_step(st, opt, b, c["ignore_index"], c["lr"])
+        _, loss, _ = O.train_step(st, opt, b, c["ignore_index"], lr_at(c, step))
         losses.append(float(loss))
         if step % 10 == 9:
             print(f"step {step + 1}: loss {losses[-1]:.4f} ({time.time() - t0:.0f} s)", flush=True)

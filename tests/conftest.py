@@ -34,7 +34,7 @@ def load_golden(name):
 def golden_names(late_fusion=False):
     """UNet training-step fixtures (oracle/make_golden.py) or the late-fusion ones (oracle/make_golden_lf.py: lf_*)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("lf_") == late_fusion
-                  and not f.startswith(("stitch_", "assemble_")))
+                  and not f.startswith(("stitch_", "assemble_", "loader_")))
 
 
 def lf_case_inputs(meta):
