@@ -29,6 +29,8 @@
 #define k_wgrad_bf16_pp k_wgrad_f16_pp
 #define conv3x3_rs_eligible conv3x3_rs_eligible_f16
 #define launch_conv3x3_rs launch_conv3x3_rs_f16
+#define conv3x3_c8_eligible conv3x3_c8_eligible_f16
+#define launch_conv3x3_c8 launch_conv3x3_c8_f16
 #endif
 
 #include <type_traits>
@@ -138,6 +140,9 @@ struct BConvP {
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
 bool conv3x3_bf16_fast_eligible(const BConvP& P);
 int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s);
+// 8-input-channel forward kernel (fu_conv_rs.hip): the network's first conv
+bool conv3x3_c8_eligible(const BConvP& P);
+int launch_conv3x3_c8(BConvP& P, const LaunchOpts& o, hipStream_t s);
 // row-stationary 16x16x32 kernel (fu_conv_rs.hip)
 bool conv3x3_rs_eligible(const BConvP& P);
 int launch_conv3x3_rs(BConvP& P, const LaunchOpts& o, hipStream_t s);

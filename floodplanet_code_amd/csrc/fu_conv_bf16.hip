@@ -1170,13 +1170,31 @@ static int wgrad_mode_env() {
 }
 #endif
 
+// Workgroups of the ping-pong kernel.  Its 8-wave workgroups (248 registers, 125 KB of LDS) take a CU each and live for the
+// whole launch (45-290 us).  At 256 of them -- one per CU, round 2 -- every kernel of the main backward chain that starts while
+// a weight-gradient launch is in flight (BatchNorm-backward finalize / apply, bilinear backward, the next dgrad) waits for
+// those workgroups to retire before it gets a single CU: in the two-stream trace the 36 finalize launches took 494 us against
+// 190 alone, the four bilinear backwards 525 against 105 (profiles/r3_*).  Launching FEWER, longer workgroups leaves CUs to
+// the critical chain from the first cycle, and the split-K slabs shrink with the workgroup count (75 -> 52 MB written and
+// re-read per layer).  Measured, same box, ms per step: 256: 5.74 / 5.75, 208: 5.61 / 5.64, 192: 5.58 / 5.61, 176: 5.59 /
+// 5.61, 160: 5.56 / 5.57, 128: 5.67 (another box, against 5.78 at 256).  (FU_WGRAD_TARGET overrides it in -DFU_EXPERIMENTS builds.)
 static int wgrad_pp_target() {
-#ifdef FU_EXPERIMENTS   // FU_WGRAD_TARGET=n: workgroups of the ping-pong kernel (256 = one per CU)
+#ifdef FU_EXPERIMENTS
   static int t = -1;
-  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 256; }
+  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 176; }
   return t;
 #else
-  return 256;
+  return 176;
+#endif
+}
+
+static int wgrad_c64_target() {
+#ifdef FU_EXPERIMENTS
+  static int t = -1;
+  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET64"); t = e ? atoi(e) : 512; }
+  return t;
+#else
+  return 512;
 #endif
 }
 
@@ -1211,8 +1229,8 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, in.opt, s);
 #endif
   else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, wgrad_pp_target(), in.opt, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
-  else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, 256, in.opt, s);
-  else st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);              // 256 threads, 64 x 64, two WGs per CU
+  else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, wgrad_pp_target(), in.opt, s);   // (same split as the ping-pong kernel: bit-identical sums)
+  else st = launch_wgrad_cfg<2, 8>(P, wgrad_c64_target(), in.opt, s);   // 256 threads, 64 x 64, two WGs per CU
   if (st) return st;
   return launch_wgrad_reduce(slab, P.S, P.Cin, Cout, cin_real, dw_oihw, db_partials, n_db_partials, db, s, true);
 }

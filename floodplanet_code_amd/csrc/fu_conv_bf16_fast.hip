@@ -568,6 +568,8 @@ int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   const int64_t t256 = (int64_t)P.B * ceil_div(P.H, 16) * ceil_div(P.W, 16);
   const bool wide = P.N >= 64 && t256 * ceil_div(P.N, 64) >= 512 && (!P.dst1 || P.D0 % 64 == 0);
   if (P.center_only) return wide ? launch_fast_cfg<2, 1>(P, o, s) : launch_fast_cfg<1, 1>(P, o, s);
+  // 8 input channels (the network's first conv): the K = 72 kernel without LDS staging (fu_conv_rs.hip)
+  if (g_bf16_tile_mode == 0 && conv3x3_c8_eligible(P)) return launch_conv3x3_c8(P, o, s);
   // Row-stationary kernel (fu_conv_rs.hip), wherever the shape is eligible and one of its tiles gives every CU two
   // workgroups.  Measured per layer against the kernels below (bench shapes, forward, tools/conv_modes.py): 5-11 % faster
   // on the 128x128, 64x64 and 32x32 layers with N >= 512 channels x tiles, equal on the two-chunk 256x256 layers, slower

@@ -477,6 +477,159 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_bf16_rs(BConvP P) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 8-input-channel convolution (the network's first conv: 8 bands, unet.py:86 `inc = DoubleConv(n_channels, 64)`), forward.
+//
+// With 8 channels a pixel is ONE 16-byte vector and the whole 3x3 window is K = 72: the row-stationary idea collapses to a
+// kernel without LDS staging.  MFMA 16x16x32 again with the weights as A and a row of 16 pixels as B; the four k-groups of a
+// k-step are the three column shifts dx (+ one zero group), the three k-steps are the kernel rows dy:
+//     B fragment of lane (pixel x, group dx), step dy  =  the 8 channels of input pixel (row + dy - 1, x + dx - 1)
+// i.e. one 16-byte global load per lane and INPUT row, kept in a register ring while the output rows walk down: output row
+// r multiplies the fragments of input rows r-1, r, r+1 (steps dy = 0, 1, 2) -- a lane never needs another lane's data.  12
+// MFMAs per 16-pixel row and 64 channels (3 steps x 4 subtiles; a quarter of each step multiplies zeros) against 36 on the
+// 16-channel-chunk kernel this replaces; the layer is bound by its 134 MB of output (B = 16, 256x256), not by the MFMAs.
+// Output / statistics exactly as the row-stationary kernel (lane = pixel with 16 consecutive channels, DPP row sums).
+// Shapes: Cin == 8 (one source, no BatchNorm prologue), N % 64 == 0, one destination, H % 16 == 0, W % 16 == 0.
+// ------------------------------------------------------------------------------------------------------------------------
+#if FU_HALF
+#define k_conv3x3_bf16_c8 k_conv3x3_f16_c8
+#endif
+
+template <int RW>     // output rows per wave; the workgroup tile is 16 columns x 4 RW rows x 64 channels
+__global__ __launch_bounds__(256) void k_conv3x3_bf16_c8(BConvP P) {
+  __shared__ float red[4 * 64 * 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lx = lane & 15, lg = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pixT = fast_div(logical, P.nCo, P.rcp_nCo);
+  const int coT = logical - pixT * P.nCo;
+  const int t2 = fast_div(pixT, P.tilesX, P.rcp_tilesX);
+  const int tx = pixT - t2 * P.tilesX;
+  const int bb = fast_div(t2, P.tilesY, P.rcp_tilesY);
+  const int ty = t2 - bb * P.tilesY;
+  const int x0 = tx * 16, y0 = ty * (4 * RW) + wm * RW, n0 = coT * 64;
+
+  // weight fragments: row m = lx of subtile s is output channel 16 (m >> 2) + 4 s + (m & 3); k-group lg = column shift dx
+  frag8_t wA[3][4];
+  {
+    const frag8_t zero = {};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const int co = n0 + 16 * (lx >> 2) + 4 * sb + (lx & 3);
+        const int tap = 3 * dy + lg;
+        wA[dy][sb] = lg < 3 ? *reinterpret_cast<const frag8_t*>(P.wpk + ((size_t)tap * P.N + co) * 8) : zero;
+      }
+  }
+  float biasv[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) biasv[c] = P.bias != nullptr ? P.bias[n0 + 16 * lg + c] : 0.f;
+
+  // this lane's input column and its fragment loader (zero outside the image and for the padding k-group)
+  const int ix = x0 + lx + lg - 1;
+  const bool colok = lg < 3 && ix >= 0 && ix < P.W;
+  const bf16_t* src = P.src0 + ((size_t)bb * P.H * P.W + (colok ? ix : 0)) * 8;
+  auto load_row = [&](int iy) {
+    const frag8_t zero = {};
+    const bool ok = colok && iy >= 0 && iy < P.H;
+    return ok ? *reinterpret_cast<const frag8_t*>(src + (size_t)iy * P.W * 8) : zero;
+  };
+
+  float ssum[16], ssq[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+  char* dbase = reinterpret_cast<char*>(P.dst0 + n0) + (size_t)(16 * lg) * 2;
+
+  // ring of four input-row fragments: rows oy-1, oy, oy+1 are live, oy+2 is in flight.  The row loop is unrolled by the
+  // ring size only (every ring index a constant); unrolled completely, hipcc hoists all the loads and the kernel needs
+  // 156 registers (two waves per SIMD) -- this store-bound kernel wants waves, not a deep private prefetch
+  static_assert(RW % 4 == 0, "rows per wave: a multiple of the ring size");
+  frag8_t pf[4];
+  pf[0] = load_row(y0 - 1); pf[1] = load_row(y0); pf[2] = load_row(y0 + 1);
+#pragma unroll 1
+  for (int rb = 0; rb < RW; rb += 4)
+  static_for<0, 4>([&](auto Rc) {
+    constexpr int k = decltype(Rc)::value;
+    const int oy = y0 + rb + k;
+    pf[(k + 3) % 4] = load_row(oy + 2);
+    f32x4 acc[4];
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) acc[sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) acc[sb] = FU_MFMA16(wA[dy][sb], pf[(k + dy) % 4], acc[sb]);
+    if (oy < P.H) {                                   // (uniform per wave; H % 16 == 0 keeps whole 16-row groups inside)
+      unsigned o[8];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const float v0 = acc[sb][0], v1 = acc[sb][1], v2 = acc[sb][2], v3 = acc[sb][3];
+        ssum[4 * sb + 0] += v0; ssum[4 * sb + 1] += v1; ssum[4 * sb + 2] += v2; ssum[4 * sb + 3] += v3;
+        ssq[4 * sb + 0] = fmaf(v0, v0, ssq[4 * sb + 0]); ssq[4 * sb + 1] = fmaf(v1, v1, ssq[4 * sb + 1]);
+        ssq[4 * sb + 2] = fmaf(v2, v2, ssq[4 * sb + 2]); ssq[4 * sb + 3] = fmaf(v3, v3, ssq[4 * sb + 3]);
+        o[2 * sb + 0] = pack_e2(f32x2{v0 + biasv[4 * sb + 0], v1 + biasv[4 * sb + 1]});
+        o[2 * sb + 1] = pack_e2(f32x2{v2 + biasv[4 * sb + 2], v3 + biasv[4 * sb + 3]});
+      }
+      char* dp = dbase + ((size_t)((bb * P.H + oy) * P.W + x0 + lx) * (size_t)P.N) * 2;
+      *reinterpret_cast<uint4*>(dp) = make_uint4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<uint4*>(dp + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+  });
+  if (P.stats) {
+    auto row_sum = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+      return v;
+    };
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { ssum[c] = row_sum(ssum[c]); ssq[c] = row_sum(ssq[c]); }
+    if (lx == 15) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        red[(wm * 64 + 16 * lg + c) * 2 + 0] = ssum[c];
+        red[(wm * 64 + 16 * lg + c) * 2 + 1] = ssq[c];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float sa = 0.f, sq = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { sa += red[(m * 64 + tid) * 2 + 0]; sq += red[(m * 64 + tid) * 2 + 1]; }
+      float* op = P.stats + ((int64_t)pixT * P.N + n0 + tid) * 2;
+      op[0] = sa;
+      op[1] = sq;
+    }
+  }
+}
+
+bool conv3x3_c8_eligible(const BConvP& P) {
+  const int64_t px = (int64_t)P.B * P.H * P.W;
+  if (P.center_only || P.Cin != 8 || P.src1 || P.a0 != nullptr || P.dst1 || (P.N % 64) || (P.H % 16) || (P.W % 16)) return false;
+  if (px * P.N * 2 >= ((int64_t)1 << 31) || px >= ((int64_t)1 << 24)) return false;
+  return true;
+}
+
+int launch_conv3x3_c8(BConvP& P, const LaunchOpts& o, hipStream_t s) {
+  const bool tall = (P.H % 64) == 0;                   // 16 x 64-pixel tiles (fewer statistics rows), else 16 x 16
+  P.tilesX = P.W / 16; P.tilesY = P.H / (tall ? 64 : 16);
+  P.nPix = P.B * P.tilesX * P.tilesY; P.nCo = P.N / 64;
+  P.rcp_nPix = host_rcp(P.nPix); P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
+  P.rcp_nCo = host_rcp(P.nCo);
+  FU_REQUIRE((int64_t)P.nPix * P.nCo * P.nPix < ((int64_t)1 << 32) && (int64_t)P.nPix * P.nCo * P.nCo < ((int64_t)1 << 32),
+             "conv3x3_c8: grid too large (%d x %d)", P.nPix, P.nCo);
+  const ProfSlot ps = o.prof;
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  if (tall) hipLaunchKernelGGL(k_conv3x3_bf16_c8<16>, dim3(P.nPix * P.nCo), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(k_conv3x3_bf16_c8<4>, dim3(P.nPix * P.nCo), dim3(256), 0, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
 bool conv3x3_rs_eligible(const BConvP& P) {
   const int64_t px = (int64_t)P.B * P.H * P.W;
   const int64_t lim = (int64_t)1 << 31;

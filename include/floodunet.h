@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FU_ABI_VERSION 3
+#define FU_ABI_VERSION 4
 #define FU_MAX_ENCODERS 6
 
 typedef struct fu_ctx fu_ctx;

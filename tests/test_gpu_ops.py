@@ -188,6 +188,11 @@ BF_SHAPES = [
     (2, 128, 64, 64, 32, 16, True),
     (1, 256, 0, 192, 32, 32, False),
     (3, 32, 0, 64, 160, 80, True),
+    # 8 input channels, no BN prologue, N % 64 == 0, H, W % 16 == 0: the first-conv kernel (k_conv3x3_*_c8) under "auto":
+    # 16 x 64 tiles (H % 64 == 0), 16 x 16 tiles, two channel tiles, the bench's tile size
+    (2, 8, 0, 64, 64, 48, False),
+    (1, 8, 0, 128, 48, 32, False),
+    (4, 8, 0, 64, 256, 256, False),
 ]
 
 
