@@ -96,6 +96,12 @@ SIGNATURES = {
     "fu_test_get_buffer": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i64)]),
     "fu_set_side_stream": (_i, [_p, _i]),
     "fu_backward_join": (_i, [_p, _p]),
+    "fu_dp_unique_id": (_i, [_p]),
+    "fu_dp_init": (_i, [_p, _p, _i, _i]),
+    "fu_dp_broadcast_state": (_i, [_p, _p]),
+    "fu_allreduce_begin": (_i, [_p, _i64, _i64, _p]),
+    "fu_allreduce_wait": (_i, [_p, _p]),
+    "fu_dp_destroy": (_i, [_p]),
     "fu_set_exact_sync": (_i, [_p, SYNC_HOOK, _p, _i, _p, _i64]),
     "fu_exact_sync_bytes": (_i64, [_p]),
     "fu_profile_read": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),

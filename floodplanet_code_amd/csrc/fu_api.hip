@@ -294,6 +294,7 @@ struct Arena {
 
 }  // namespace
 
+struct Dp;
 struct fu_ctx {
   fu_config cfg;
   Prec prec;
@@ -352,6 +353,7 @@ struct fu_ctx {
   float* adam_m = nullptr;        // bound (caller-owned, fu_bind_adam_state): the moments outlive the context
   float* adam_v = nullptr;
   Profiler prof;
+  struct Dp* dp = nullptr;            // fu_dp_init: RCCL communicator, communication stream, events
   std::vector<PackTable> pack_tabs;   // <= MAX_PACK layers per launch
   // state
   int last_batch = 0;
@@ -1129,6 +1131,7 @@ int fu_destroy(fu_ctx* c) {
   if (!c) return FU_OK;
   (void)hipSetDevice(c->cfg.device);
   (void)hipDeviceSynchronize();
+  (void)fu_dp_destroy(c);
   for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
   if (c->side) {
     if (c->side_lo) (void)hipStreamDestroy(c->side_lo);
@@ -1476,6 +1479,146 @@ int fu_assemble_tiles(const float* const* srcs, const int32_t* src_channels, int
   FU_REQUIRE(srcs && src_channels && out && B >= 1 && H >= 1 && W >= 1, "fu_assemble_tiles: bad argument");
   return launch_assemble_tiles(srcs, src_channels, n_src, B, H, W, valid_h, valid_w, norm_mode, global_mean, global_std,
                                pad_value, out, mean_out, std_out, (hipStream_t)stream);
+}
+
+// ---- data-parallel collective behind the C ABI (fu_allreduce_begin / wait) ----------------------------------
+// RCCL is resolved at run time (dlopen): the library has no link-time dependency on it, a process that never calls
+// fu_dp_init never loads it, and inside a torch process the copy torch already loaded is the one that is used.
+}  // extern "C"
+#include <dlfcn.h>
+struct Dp {
+  void* lib = nullptr;
+  void* comm = nullptr;
+  hipStream_t stream = nullptr;       // communication stream: all-reduces run here, beside the backward kernels
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int rank = 0, world = 1;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, fu_dp_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+namespace {
+constexpr int kNcclFloat32 = 7, kNcclInt64 = 4, kNcclSum = 0;      // ncclDataType_t / ncclRedOp_t values of rccl.h
+void* rccl_handle() {
+  static void* h = nullptr;
+  if (h) return h;
+  for (const char* n : {"librccl.so", "librccl.so.1"}) {           // a copy that is already in the process (torch's) first
+    h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (h) return h;
+  }
+  for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) return h;
+  }
+  return nullptr;
+}
+template <typename F> bool sym(void* lib, const char* name, F* out) {
+  *out = reinterpret_cast<F>(dlsym(lib, name));
+  return *out != nullptr;
+}
+int dp_load(Dp* d) {
+  d->lib = rccl_handle();
+  if (!d->lib) { set_error("fu_dp: librccl.so not found (%s)", dlerror()); return FU_ERR_UNSUPPORTED; }
+  const bool ok = sym(d->lib, "ncclGetUniqueId", &d->GetUniqueId) && sym(d->lib, "ncclCommInitRank", &d->CommInitRank) &&
+                  sym(d->lib, "ncclCommDestroy", &d->CommDestroy) && sym(d->lib, "ncclAllReduce", &d->AllReduce) &&
+                  sym(d->lib, "ncclBroadcast", &d->Broadcast) && sym(d->lib, "ncclGetErrorString", &d->GetErrorString);
+  if (!ok) { set_error("fu_dp: librccl.so lacks an expected symbol"); return FU_ERR_UNSUPPORTED; }
+  return 0;
+}
+#define FU_NCCL(d, expr)                                                                      \
+  do {                                                                                        \
+    const int _r = (expr);                                                                    \
+    if (_r != 0) { set_error("%s failed: %s", #expr, (d)->GetErrorString(_r)); return FU_ERR_HIP; } \
+  } while (0)
+}  // namespace
+extern "C" {
+
+int fu_dp_unique_id(fu_dp_id* id) {
+  FU_REQUIRE(id, "fu_dp_unique_id: null argument");
+  Dp d;
+  FU_TRY(dp_load(&d));
+  FU_NCCL(&d, d.GetUniqueId(id));
+  return FU_OK;
+}
+
+int fu_dp_init(fu_ctx* c, const fu_dp_id* id, int rank, int world) {
+  FU_REQUIRE(c && id && world >= 1 && rank >= 0 && rank < world, "fu_dp_init: bad argument (rank %d of %d)", rank, world);
+  FU_REQUIRE(c->dp == nullptr, "fu_dp_init: the context already has a communicator");
+  FU_HIP_CHECK(hipSetDevice(c->cfg.device));
+  Dp* d = new (std::nothrow) Dp();
+  FU_REQUIRE(d, "out of host memory");
+  int st = dp_load(d);
+  if (st == 0) {
+    const int r = d->CommInitRank(&d->comm, world, *id, rank);
+    if (r != 0) { set_error("ncclCommInitRank failed: %s", d->GetErrorString(r)); st = FU_ERR_HIP; }
+  }
+  if (st == 0 && (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
+                  hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess)) {
+    set_error("fu_dp_init: stream / event creation failed");
+    st = FU_ERR_HIP;
+  }
+  if (st != 0) {
+    if (d->comm) (void)d->CommDestroy(d->comm);
+    delete d;
+    return st;
+  }
+  d->rank = rank; d->world = world;
+  c->dp = d;
+  return FU_OK;
+}
+
+int fu_dp_destroy(fu_ctx* c) {
+  if (!c || !c->dp) return FU_OK;
+  Dp* d = c->dp;
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->comm) (void)d->CommDestroy(d->comm);
+  if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+  if (d->ev_done) (void)hipEventDestroy(d->ev_done);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  c->dp = nullptr;
+  return FU_OK;
+}
+
+int fu_dp_broadcast_state(fu_ctx* c, fu_stream stream) {
+  FU_REQUIRE(c && c->dp, "fu_dp_broadcast_state: no communicator (fu_dp_init)");
+  FU_REQUIRE(c->P && c->RM && c->RV && c->NBT, "fu_dp_broadcast_state: buffers not bound (fu_bind_buffers)");
+  Dp* d = c->dp;
+  hipStream_t s = (hipStream_t)stream;
+  FU_NCCL(d, d->Broadcast(c->P, c->P, (size_t)c->total_params, kNcclFloat32, 0, d->comm, s));
+  FU_NCCL(d, d->Broadcast(c->RM, c->RM, (size_t)c->total_bn, kNcclFloat32, 0, d->comm, s));
+  FU_NCCL(d, d->Broadcast(c->RV, c->RV, (size_t)c->total_bn, kNcclFloat32, 0, d->comm, s));
+  FU_NCCL(d, d->Broadcast(c->NBT, c->NBT, c->bns.size(), kNcclInt64, 0, d->comm, s));
+  c->packed_dirty = true;
+  return FU_OK;
+}
+
+int fu_allreduce_begin(fu_ctx* c, int64_t flat_offset, int64_t numel, fu_stream stream) {
+  FU_REQUIRE(c && c->dp, "fu_allreduce_begin: no communicator (fu_dp_init)");
+  FU_REQUIRE(c->G, "fu_allreduce_begin: no gradient buffer bound");
+  FU_REQUIRE(flat_offset >= 0 && numel >= 0 && flat_offset + numel <= c->total_params,
+             "fu_allreduce_begin: range [%lld, +%lld) outside the %lld gradient elements", (long long)flat_offset,
+             (long long)numel, (long long)c->total_params);
+  if (numel == 0) return FU_OK;
+  Dp* d = c->dp;
+  // the bucket's gradients are final in `stream` order (the caller joined the side stream: fu_backward_join / a joining
+  // fu_backward_block); the all-reduce starts behind them on the communication stream, the caller's stream moves on
+  FU_HIP_CHECK(hipEventRecord(d->ev_ready, (hipStream_t)stream));
+  FU_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_ready, 0));
+  float* g = c->G + flat_offset;
+  FU_NCCL(d, d->AllReduce(g, g, (size_t)numel, kNcclFloat32, kNcclSum, d->comm, d->stream));
+  return FU_OK;
+}
+
+int fu_allreduce_wait(fu_ctx* c, fu_stream stream) {
+  FU_REQUIRE(c && c->dp, "fu_allreduce_wait: no communicator (fu_dp_init)");
+  Dp* d = c->dp;
+  FU_HIP_CHECK(hipEventRecord(d->ev_done, d->stream));
+  FU_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, d->ev_done, 0));
+  return FU_OK;
 }
 
 // ---- single operators --------------------------------------------------------------------------------

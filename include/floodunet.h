@@ -21,6 +21,7 @@
  *   fu_augment                  torchvision hflip / vflip / rotate of sample_transforms + apply_transforms
  *                                                                            st_water_seg/datasets/base_dataset.py:494-555
  *   fu_block_param_range        (new) gradient bucket of one backward block, for RCCL all-reduce overlap
+ *   fu_dp_* / fu_allreduce_*    (new) the bucketed gradient all-reduce itself, RCCL resolved at run time
  *   fu_op_*                     single operators for per-op parity tests (conv2d, batch_norm, max_pool2d,
  *                               upsample, cross_entropy as used in unet.py / water_seg_model.py)
  *
@@ -205,6 +206,25 @@ int fu_zero_grads(fu_ctx* ctx, fu_stream stream);
 typedef int (*fu_sync_hook)(void* user, int64_t n_elems, int is_double);
 int fu_set_exact_sync(fu_ctx* ctx, fu_sync_hook hook, void* user, int world, void* exchange, int64_t exchange_bytes);
 int64_t fu_exact_sync_bytes(const fu_ctx* ctx);
+
+/* ---- gradient all-reduce behind the C ABI (one process per GPU, RCCL over xGMI) ---------------
+ * For hosts without torch.distributed.  RCCL (librccl.so) is resolved at run time on the first of these calls; nothing
+ * else in the library depends on it.  One communicator per context.  The semantics are DESIGN.md section 6's: every rank
+ * runs the step on its own tiles; per backward bucket (a contiguous range of the flat gradient buffer,
+ * fu_block_param_range) fu_allreduce_begin starts a SUM all-reduce on the context's communication stream, ordered behind
+ * the work enqueued on `stream` so far (the bucket's gradients must be final there: fu_backward_block in side-stream mode
+ * 0 / 1, or fu_backward_join in mode 2), while the remaining backward blocks keep `stream` busy; fu_allreduce_wait makes
+ * `stream` wait for every all-reduce begun so far; then fu_adam_step(..., grad_scale = 1 / world, ...).
+ *   rank 0: fu_dp_unique_id(&id); ship the 128 bytes to the other ranks by any means (file, socket, MPI, environment);
+ *   every rank: fu_dp_init(ctx, &id, rank, world); fu_dp_broadcast_state(ctx, stream) once (rank 0's parameters and
+ *   BatchNorm buffers to everyone); ... steps ...; fu_dp_destroy (fu_destroy calls it). */
+typedef struct fu_dp_id { char bytes[128]; } fu_dp_id;   /* ncclUniqueId */
+int fu_dp_unique_id(fu_dp_id* id);
+int fu_dp_init(fu_ctx* ctx, const fu_dp_id* id, int rank, int world);
+int fu_dp_broadcast_state(fu_ctx* ctx, fu_stream stream);
+int fu_allreduce_begin(fu_ctx* ctx, int64_t flat_offset, int64_t numel, fu_stream stream);
+int fu_allreduce_wait(fu_ctx* ctx, fu_stream stream);
+int fu_dp_destroy(fu_ctx* ctx);
 
 /* ---- on-GPU tile augmentation (datasets/base_dataset.py:494-555) ------- */
 /* Per sample b: hflip (flags[b] & 1), then vflip (& 2), then rotate by angles_deg[b] (& 4) with torchvision's
