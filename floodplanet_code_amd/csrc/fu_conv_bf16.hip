@@ -1176,15 +1176,18 @@ static int wgrad_mode_env() {
 // those workgroups to retire before it gets a single CU: in the two-stream trace the 36 finalize launches took 494 us against
 // 190 alone, the four bilinear backwards 525 against 105 (profiles/r3_*).  Launching FEWER, longer workgroups leaves CUs to
 // the critical chain from the first cycle, and the split-K slabs shrink with the workgroup count (75 -> 52 MB written and
-// re-read per layer).  Measured, same box, ms per step: 256: 5.74 / 5.75, 208: 5.61 / 5.64, 192: 5.58 / 5.61, 176: 5.59 /
-// 5.61, 160: 5.56 / 5.57, 128: 5.67 (another box, against 5.78 at 256).  (FU_WGRAD_TARGET overrides it in -DFU_EXPERIMENTS builds.)
+// re-read per layer).  Measured, same box, ms per step | conv class TFLOP/s event-timed in the step: 256: 5.74 / 5.75 | 835 /
+// 856, 208: 5.61 / 5.64 | 830 / 827, 192: 5.58 / 5.61 | 790 / 790, 176: 5.59 / 5.61 | 793 / 789, 160: 5.56 / 5.57 | 780 / 790,
+// 128: 5.67 (another box, against 5.78 at 256).  Below 208 the step gains another 0.5 % while the dgrad launches -- which then
+// share the GPU with the longer-running weight-gradient launch of the layer before -- lose 5 %: 208 takes most of the one
+// without the other.  (FU_WGRAD_TARGET overrides it in -DFU_EXPERIMENTS builds.)
 static int wgrad_pp_target() {
 #ifdef FU_EXPERIMENTS
   static int t = -1;
-  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 176; }
+  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 208; }
   return t;
 #else
-  return 176;
+  return 208;
 #endif
 }
 
