@@ -77,6 +77,7 @@ SIGNATURES = {
     "fu_scale_loss_grad": (_i, [_p, _p, _p]),
     "fu_adam_step": (_i, [_p, _d, _d, _d, _d, _i64, _d, _p]),
     "fu_adam_state": (_i, [_p, C.POINTER(_p), C.POINTER(_p)]),
+    "fu_fp16_guard_state": (_i, [_p, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "fu_adam_scalars": (_i, [_d, _d, _d, _d, _i64, _d, C.POINTER(C.c_float)]),
     "fu_adam_step_dev": (_i, [_p, _p, _p]),
     "fu_zero_grads": (_i, [_p, _p]),

@@ -234,7 +234,11 @@ struct LaunchOpts {
 };
 // out = dlogits * (*up_scale_dev or 1) * (S or 1); scale != null (fp16): S chosen from max|dlogits * up| and written to scale[0..1]
 int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const float* up_scale_dev,
-                         float* partials /* >= 256 floats */, float* scale /* [2] or null */, hipStream_t s);
+                         float* partials /* >= 256 floats */, float* scale /* [2] or null */, hipStream_t s,
+                         const int* guard = nullptr /* fp16 guard words: [2] = back-off exponent */);
+// fp16 guard: guard[0] <- 1 if a gradient is not finite; bookkeeping after the (possibly skipped) Adam launch
+int launch_grad_finite_check(const float* g, int64_t n, int* guard, hipStream_t s);
+int launch_guard_book(int* guard, hipStream_t s);
 
 #ifdef FU_EXPERIMENTS   // ablation-by-skip in variant builds only (tools/build_variant.sh exp -DFU_EXPERIMENTS): FU_EXP_SKIP bit mask,
 // 1 = BN forward finalize, 2 = BN backward finalize, 4 = wgrad slab reduce + transpose, 8 = weight pack, 16 = BN backward apply,
@@ -402,8 +406,9 @@ int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                double eps, int64_t step, double grad_scale, hipStream_t s);
+                double eps, int64_t step, double grad_scale, hipStream_t s, const int* skip = nullptr);
 void adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale, float out[7]);
-int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s);
+int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s,
+                    const int* skip = nullptr);
 
 }  // namespace fu

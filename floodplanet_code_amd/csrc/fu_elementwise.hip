@@ -2007,12 +2007,15 @@ int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t
 // ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor update order; water_seg_model.py:200)
 // ------------------------------------------------------------------------------------------------
+// skip (optional, fp16 mode): device flag set by k_grad_finite_check when a gradient of this step is not finite -- the whole
+// update is then left out (parameters and moments untouched), as a GradScaler skips such a step
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, int64_t n, float w1, float beta2, float omb2, float bc2_sqrt,
-                       float eps, float neg_step, float gscale) {
+                       float eps, float neg_step, float gscale, const int* __restrict__ skip) {
   // every operation rounds on its own, in ATen's order (no fma contraction): with identical inputs the update is the
   // same float sequence as torch's CPU Adam (lerp_ / mul_ / addcmul_ / sqrt / div / add_ / addcdiv_)
 #pragma clang fp contract(off)
+  if (skip && *skip) return;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     float mi = m[i], vi = v[i];
@@ -2041,11 +2044,43 @@ void adam_scalars(double lr, double beta1, double beta2, double eps, int64_t ste
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                double eps, int64_t step, double grad_scale, hipStream_t s) {
+                double eps, int64_t step, double grad_scale, hipStream_t s, const int* skip) {
   float sc[7];
   adam_scalars(lr, beta1, beta2, eps, step, grad_scale, sc);
   hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, sc[0], sc[1], sc[2], sc[3],
-                     sc[4], sc[5], sc[6]);
+                     sc[4], sc[5], sc[6], skip);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp16 guard.  The loss scale is chosen once per backward from max|dL/dlogits|; what the chain multiplies on top (a
+// BatchNorm with a tiny variance: gamma * invstd in the hundreds) can still push an fp16 gradient map past 65504.  The inf /
+// NaN then reaches the flat gradient buffer; guard[0] flags it, the Adam launch of that step does nothing, and the next
+// backward's scale is halved once more (guard[2] = back-off exponent, taken back by one every 64 clean steps).
+//   guard[0] non-finite flag of the running step, [1] steps skipped so far, [2] back-off exponent, [3] clean steps since
+__global__ __launch_bounds__(256) void k_grad_finite_check(const float* __restrict__ g, int64_t n, int* __restrict__ guard) {
+  bool bad = false;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      bad = bad || !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f) || !(fabsf(v.z) <= 3.0e38f) || !(fabsf(v.w) <= 3.0e38f);
+    } else {
+      for (int64_t k = i; k < n; ++k) bad = bad || !(fabsf(g[k]) <= 3.0e38f);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(guard, 1);
+}
+__global__ void k_guard_book(int* __restrict__ guard) {
+  if (guard[0]) { guard[1] += 1; guard[2] = min(guard[2] + 1, 14); guard[3] = 0; guard[0] = 0; }
+  else if (++guard[3] >= 64) { guard[3] = 0; guard[2] = max(guard[2] - 1, 0); }
+}
+int launch_grad_finite_check(const float* g, int64_t n, int* guard, hipStream_t s) {
+  hipLaunchKernelGGL(k_grad_finite_check, dim3(grid_for(n, 1024 * 4, 2048)), dim3(256), 0, s, g, n, guard);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+int launch_guard_book(int* guard, hipStream_t s) {
+  hipLaunchKernelGGL(k_guard_book, dim3(1), dim3(1), 0, s, guard);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -2053,8 +2088,9 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double 
 // The same update with its scalars read from DEVICE memory: a captured (hipGraph) step replays this launch unchanged while
 // the step count -- and with it the bias corrections -- moves on; the caller refreshes the seven floats before each replay.
 __global__ void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                           float* __restrict__ v, int64_t n, const float* __restrict__ sc) {
+                           float* __restrict__ v, int64_t n, const float* __restrict__ sc, const int* __restrict__ skip) {
 #pragma clang fp contract(off)
+  if (skip && *skip) return;
   const float w1 = sc[0], beta2 = sc[1], omb2 = sc[2], bc2_sqrt = sc[3], eps = sc[4], neg_step = sc[5], gscale = sc[6];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
@@ -2071,8 +2107,9 @@ __global__ void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, f
     v[i] = vi;
   }
 }
-int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_adam_dev, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, scalars_dev);
+int launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* scalars_dev, hipStream_t s,
+                    const int* skip) {
+  hipLaunchKernelGGL(k_adam_dev, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, scalars_dev, skip);
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -2102,7 +2139,8 @@ __global__ __launch_bounds__(256) void k_absmax_partial(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void k_loss_grad_eff(const float* __restrict__ x, float* __restrict__ out, int64_t n,
                                                        const float* __restrict__ partials, int nPart,
-                                                       const float* __restrict__ up, float* __restrict__ scale) {
+                                                       const float* __restrict__ up, float* __restrict__ scale,
+                                                       const int* __restrict__ guard) {
   __shared__ float sm[4];
   const float upv = up ? *up : 1.f;
   float f = upv;
@@ -2115,6 +2153,7 @@ __global__ __launch_bounds__(256) void k_loss_grad_eff(const float* __restrict__
     m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) * fabsf(upv);
     int e = 0;
     if (m > 0.f && m <= 3.0e38f) { (void)frexpf(m, &e); e = 6 - e; }  // m = f * 2^e', f in [0.5, 1)  ->  m * 2^(6 - e') in [32, 64)
+    if (guard) e -= guard[2];                                        // back-off after overflowed steps (k_guard_book)
     e = min(max(e, -60), 60);
     const float S = ldexpf(1.f, e);
     if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = ldexpf(1.f, -e); }
@@ -2123,7 +2162,7 @@ __global__ __launch_bounds__(256) void k_loss_grad_eff(const float* __restrict__
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x[i] * f;
 }
 int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const float* up_scale_dev, float* partials,
-                         float* scale, hipStream_t s) {
+                         float* scale, hipStream_t s, const int* guard) {
   int g = 0;
   if (scale) {
     g = grid_for(n, 256 * 16, 256);
@@ -2131,7 +2170,7 @@ int launch_loss_grad_eff(const float* dlogits, float* out, int64_t n, const floa
     FU_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_loss_grad_eff, dim3(grid_for(n, 256 * 4, 2048)), dim3(256), 0, s, dlogits, out, n, partials, g,
-                     up_scale_dev, scale);
+                     up_scale_dev, scale, guard);
   FU_LAUNCH_CHECK();
   return 0;
 }

@@ -415,6 +415,13 @@ class HipUNet(nn.Module):
                                        float(grad_scale), self._stream(dev)))
         self._eval_dirty = True
 
+    def fp16_guard_state(self) -> Tuple[int, int]:
+        """(optimiser steps skipped because a gradient was not finite, current loss-scale back-off exponent) -- fp16 mode;
+        (0, 0) otherwise.  Synchronises the device."""
+        n, e = C.c_int64(), C.c_int32()
+        check(_lib.load().fu_fp16_guard_state(self._ctx, C.byref(n), C.byref(e)))
+        return n.value, e.value
+
     def flops_per_tile(self) -> Tuple[float, float]:
         f, t = C.c_double(), C.c_double()
         check(_lib.load().fu_flops_per_tile(self._ctx, C.byref(f), C.byref(t)))

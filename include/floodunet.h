@@ -65,7 +65,8 @@ enum fu_precision {
                 * rate), fp32 accumulation, fp32 master weights, BN statistics, loss and Dice reductions (BASELINE configs[3]:
                 * "mixed fp16 with fp32 Dice reduction").  The gradient maps carry a power-of-two loss scale chosen on the
                 * device from max|dL/dlogits| at the start of every backward and removed where parameter gradients are
-                * written: the flat gradient buffer holds true gradients, no caller-side GradScaler is needed.  Inputs are
+                * written: the flat gradient buffer holds true gradients, no caller-side GradScaler is needed (a step whose
+                * gradients overflowed all the same is skipped on the device: fu_fp16_guard_state).  Inputs are
                 * expected in fp16's range (the reference scales every sensor to [0, 1], datasets/floodplanet.py:347-525). */
 };
 
@@ -183,6 +184,12 @@ int fu_bind_adam_state(fu_ctx* ctx, float* exp_avg, float* exp_avg_sq);
 int fu_adam_step(fu_ctx* ctx, double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                  fu_stream stream);
 int fu_adam_state(fu_ctx* ctx, float** exp_avg, float** exp_avg_sq); /* the bound pointers (NULL when none) */
+/* FU_F16 only: the device-side loss scale follows max|dL/dlogits|, but a layer deep in the chain (a BatchNorm with a tiny
+ * variance) can still overflow an fp16 gradient map.  fu_adam_step[_dev] therefore checks the gradient buffer on the device;
+ * if a value is not finite the update of that step is left out entirely (parameters and moments untouched) and the next
+ * backward scales the loss by a further 1/2 (taken back by one every 64 clean steps) -- what a GradScaler does, without a
+ * host read.  This call reads the counters (it synchronises the device): steps skipped so far, current back-off exponent. */
+int fu_fp16_guard_state(fu_ctx* ctx, int64_t* skipped_steps, int32_t* backoff_exponent);
 /* The same update for a CAPTURED step (hipGraph): the seven float scalars of the kernel -- which depend on the step count --
  * are read from device memory, so one captured launch serves every replay.  fu_adam_scalars forms them on the host exactly
  * as fu_adam_step does (out[7]: 1-beta1, beta2, 1-beta2, sqrt(bias_correction2), eps, -lr/bias_correction1, grad_scale);

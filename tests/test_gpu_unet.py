@@ -543,6 +543,50 @@ def test_repeated_backward_of_one_loss_gives_the_same_gradients(prec):
     assert rel(g1, 4.0 * g_plain) <= 1e-6
 
 
+def test_fp16_overflowing_step_is_skipped_and_the_loss_scale_backs_off():
+    """fp16 mode: the device-side loss scale follows max|dL/dlogits| (scaled into [32, 64)); what the chain multiplies on top
+    can still push a gradient map past 65504 -- here OutConv weights of 3e3, so that the very first fp16 gradient map
+    (dlogits x W) overflows.  The inf / NaN then sits in the gradient buffer: that step's Adam launch must leave
+    parameters and moments untouched, the next backward scales the loss down further, and after a few skipped steps the
+    updates go through again with finite values everywhere (what a GradScaler does, on the device)."""
+    st = O.make_state(8, 3, 16, True, seed=1)
+    st["outc.conv.weight"][:] = st["outc.conv.weight"].sign() * 3.0e3
+    batch = O.make_batch(2, 8, 64, 64, seed=2)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    net = HipUNet(8, 3, base_channels=16, precision="fp16")
+    net.load_state_dict(st)
+    net.to(DEV).train()
+    net.train_step(x, t, 0)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(net.flat_grads()).all()             # the scenario really overflows
+    p0, m0 = net.flat_parameters().clone(), net.adam_state()[0].clone()
+    net.adam_step(1e-3, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(net.flat_parameters(), p0) and torch.equal(net.adam_state()[0], m0)      # skipped: nothing moved
+    assert net.fp16_guard_state() == (1, 1)
+    applied_at = None
+    for step in range(2, 14):
+        net.train_step(x, t, 0)
+        finite = bool(torch.isfinite(net.flat_grads()).all())
+        before = net.flat_parameters().clone()
+        net.adam_step(1e-3, step)
+        torch.cuda.synchronize()
+        moved = not torch.equal(net.flat_parameters(), before)
+        assert moved == finite                                    # a step is applied exactly when its gradients are finite
+        if moved and applied_at is None:
+            applied_at = step
+    skipped, backoff = net.fp16_guard_state()
+    assert applied_at is not None and 1 <= skipped < 12 and backoff >= 1, (applied_at, skipped, backoff)
+    assert torch.isfinite(net.flat_parameters()).all() and torch.isfinite(net.adam_state()[0]).all()
+    # bf16 / fp32 contexts: no guard, nothing to report
+    n32 = HipUNet(8, 3, base_channels=16)
+    n32.load_state_dict(st)
+    n32.to(DEV).train()
+    n32.train_step(x, t, 0)
+    n32.adam_step(1e-3, 1)
+    assert n32.fp16_guard_state() == (0, 0)
+
+
 def test_plugin_path_uses_fused_adam_and_keeps_torch_semantics():
     """configure_optimizers() returns HipAdam (one fused launch); the Lightning loop zero_grad / training_step / backward /
     step gives the same parameters as torch.optim.Adam driven through the same loop (FU_TORCH_ADAM=1), the upstream
