@@ -803,7 +803,9 @@ int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, voi
 // ------------------------------------------------------------------------------------------------
 // bilinear x2 (align_corners=True) of relu(a*y+b), zero-padded to outH x outW (F.pad of unet.py:57-62)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// R consecutive output rows per thread: one row per thread was latency-bound (a wave lived ~2.5 us for one 16-byte store
+// per lane: 3.0 TB/s on the 256x256 level); the 4R loads of a thread are independent and issued ahead of the arithmetic
+template <typename T, int R>
 __global__ __launch_bounds__(256) void k_upsample2(const T* __restrict__ src, const float* __restrict__ a,
                                                    const float* __restrict__ b, T* __restrict__ dst, int H, int W, int C,
                                                    int outH, int outW, int py0, int px0, UpTables t, int CV,
@@ -812,37 +814,60 @@ __global__ __launch_bounds__(256) void k_upsample2(const T* __restrict__ src, co
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= outW * CV) return;
   const int ox = fast_div(item, CV, rcpCV), cv = item - ox * CV;
-  const int oy = blockIdx.y, bb = blockIdx.z;
-  float o[V];
+  const int oy0 = blockIdx.y * R, bb = blockIdx.z;
+  const int ux = ox - px0;
+  const bool in_x = ux >= 0 && ux < 2 * W;
+  float av[V], bv[V];
+  const bool bn = a != nullptr;
+  if (bn) load_coef<V>(a, b, cv * V, av, bv);
+  // source index and weight as ATen computes them (area_pixel_compute_scale<float>, align_corners=True): the same
+  // float expressions as the host tables of the backward pass (fu_api.hip build_axis), evaluated here so that no
+  // load depends on a table load
+  const float sx = t.scale_x * (float)ux;
+  const int x0 = in_x ? (int)sx : 0;
+  const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f), wx0 = 1.f - wx1;
+  const T* base = src + (size_t)bb * H * W * C + cv * V;
+  float z00[R][V], z01[R][V], z10[R][V], z11[R][V], wy1[R];
+  bool in[R];
 #pragma unroll
-  for (int j = 0; j < V; ++j) o[j] = 0.f;
-  const int uy = oy - py0, ux = ox - px0;                       // uy is block-uniform: its table entries are scalar loads
-  if (uy >= 0 && uy < 2 * H && ux >= 0 && ux < 2 * W) {
-    float av[V], bv[V];
-    const bool bn = a != nullptr;
-    if (bn) load_coef<V>(a, b, cv * V, av, bv);
-    // source index and weight as ATen computes them (area_pixel_compute_scale<float>, align_corners=True): the same
-    // float expressions as the host tables of the backward pass (fu_api.hip build_axis), evaluated here so that no
-    // load depends on a table load
-    const float sy = t.scale_y * (float)uy, sx = t.scale_x * (float)ux;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float wy1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
-    const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-    const T* base = src + (size_t)bb * H * W * C + cv * V;
-    float z00[V], z01[V], z10[V], z11[V];
-    load_act<T, V>(base + ((size_t)y0 * W + x0) * C, av, bv, bn, z00);
-    load_act<T, V>(base + ((size_t)y0 * W + x1) * C, av, bv, bn, z01);
-    load_act<T, V>(base + ((size_t)y1 * W + x0) * C, av, bv, bn, z10);
-    load_act<T, V>(base + ((size_t)y1 * W + x1) * C, av, bv, bn, z11);
-#pragma unroll
-    for (int j = 0; j < V; ++j)
-      o[j] = wy0 * (wx0 * z00[j] + wx1 * z01[j]) + wy1 * (wx0 * z10[j] + wx1 * z11[j]);
+  for (int r = 0; r < R; ++r) {
+    const int uy = oy0 + r - py0;                               // block-uniform
+    in[r] = in_x && uy >= 0 && uy < 2 * H && oy0 + r < outH;
+    const float sy = t.scale_y * (float)uy;
+    const int y0 = in[r] ? (int)sy : 0;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    wy1[r] = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
+    VecIO<T>::load(base + ((size_t)y0 * W + x0) * C, z00[r]);
+    VecIO<T>::load(base + ((size_t)y0 * W + x1) * C, z01[r]);
+    VecIO<T>::load(base + ((size_t)y1 * W + x0) * C, z10[r]);
+    VecIO<T>::load(base + ((size_t)y1 * W + x1) * C, z11[r]);
   }
-  VecIO<T>::store(dst + ((size_t)(bb * outH + oy) * outW + ox) * C + cv * V, o);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (oy0 + r >= outH) break;
+    float o[V];
+    const float wy0 = 1.f - wy1[r];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float p00 = z00[r][j], p01 = z01[r][j], p10 = z10[r][j], p11 = z11[r][j];
+      if (bn) {
+        p00 = bn_act(av[j], p00, bv[j]); p01 = bn_act(av[j], p01, bv[j]);
+        p10 = bn_act(av[j], p10, bv[j]); p11 = bn_act(av[j], p11, bv[j]);
+      }
+      o[j] = in[r] ? wy0 * (wx0 * p00 + wx1 * p01) + wy1[r] * (wx0 * p10 + wx1 * p11) : 0.f;
+    }
+    VecIO<T>::store(dst + ((size_t)(bb * outH + oy0 + r) * outW + ox) * C + cv * V, o);
+  }
 }
 
-template <typename T>
+// Backward of the bilinear x2 resize as a walk down the output rows: a thread owns an input column (16 bytes of channels)
+// and a strip of TY input rows; for every output row that touches the strip it reduces the row's gradient along x with
+// the column's tap list (<= UP_BWD_MAX taps, held in registers) and adds the result to the one or two input rows the
+// output row interpolates between (y_i0 / y_i1 / y_w1, the forward tables; y_i0 never decreases, so two running
+// accumulators suffice).  Every output row is read once per strip (the first version gathered per input pixel: every output
+// row was read by each of the two or three input rows under it, from different workgroups).
+template <typename T, int TY>
 __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gdst, T* __restrict__ gsrc, int H, int W,
                                                        int C, int outH, int outW, int py0, int px0, UpTables t, int CV,
                                                        unsigned rcpCV) {
@@ -850,35 +875,58 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gds
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= W * CV) return;
   const int ix = fast_div(item, CV, rcpCV), cv = item - ix * CV;
-  const int iy = blockIdx.y, bb = blockIdx.z;
-  float acc[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) acc[j] = 0.f;
-  const T* base = gdst + (size_t)bb * outH * outW * C + cv * V;
-  // the column list of this lane once, ahead of the row loop (it was re-read from the table inside it, a dependent load
-  // and a data-dependent break per tap); same taps in the same order, so the sums are unchanged
+  const int iy0 = blockIdx.y * TY, iy1 = min(iy0 + TY, H), bb = blockIdx.z;
   int xo[UP_BWD_MAX];
   float xw[UP_BWD_MAX];
 #pragma unroll
   for (int jx = 0; jx < UP_BWD_MAX; ++jx) { xo[jx] = t.xb_o[ix * UP_BWD_MAX + jx]; xw[jx] = t.xb_w[ix * UP_BWD_MAX + jx]; }
-  for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
-    const int oy = t.yb_o[iy * UP_BWD_MAX + jy];                // block-uniform
-    if (oy < 0) break;
-    const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
-    const T* rowp = base + (size_t)(oy + py0) * outW * C;
+  // the output rows that touch the strip: the gather lists are in ascending order (block-uniform scalar loads)
+  const int lo = t.yb_o[iy0 * UP_BWD_MAX];
+  int hi = lo;
+#pragma unroll
+  for (int j = 0; j < UP_BWD_MAX; ++j) hi = max(hi, t.yb_o[(iy1 - 1) * UP_BWD_MAX + j]);
+  const T* base = gdst + ((size_t)bb * outH + py0) * outW * C + (size_t)px0 * C + cv * V;
+  T* out = gsrc + (size_t)bb * H * W * C + (size_t)ix * C + cv * V;
+  float accA[V], accB[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+  int cur = t.y_i0[lo];
+  for (int uy = lo; uy <= hi; ++uy) {
+    const int a0 = t.y_i0[uy], a1 = t.y_i1[uy];
+    const float w1 = t.y_w1[uy];
+    while (cur < a0) {                                           // block-uniform
+      if (cur >= iy0 && cur < iy1) VecIO<T>::store(out + (size_t)cur * W * C, accA);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { accA[j] = accB[j]; accB[j] = 0.f; }
+      ++cur;
+    }
+    const T* rowp = base + (size_t)uy * outW * C;
+    float gv[UP_BWD_MAX][V];
 #pragma unroll
     for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
-      if (__builtin_amdgcn_ballot_w64(xo[jx] >= 0) == 0) break;  // wave-uniform: lists are filled front to back
-      if (xo[jx] >= 0) {
-        const float w = wy * xw[jx];
-        float gv[V];
-        VecIO<T>::load(rowp + (size_t)(xo[jx] + px0) * C, gv);
+      if (xo[jx] >= 0) VecIO<T>::load(rowp + (size_t)xo[jx] * C, gv[jx]);
+      else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += w * gv[j];
+        for (int j = 0; j < V; ++j) gv[jx][j] = 0.f;
       }
     }
+    float r[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      r[j] = xw[0] * gv[0][j];
+#pragma unroll
+      for (int jx = 1; jx < UP_BWD_MAX; ++jx) r[j] += xw[jx] * gv[jx][j];
+    }
+    const float w0 = 1.f - w1;
+    const bool same = a1 == cur;                                 // the last input row: both taps are that row
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      accA[j] += w0 * r[j];
+      if (same) accA[j] += w1 * r[j]; else accB[j] += w1 * r[j];
+    }
   }
-  VecIO<T>::store(gsrc + ((size_t)(bb * H + iy) * W + ix) * C + cv * V, acc);
+  if (cur >= iy0 && cur < iy1) VecIO<T>::store(out + (size_t)cur * W * C, accA);
+  if (cur + 1 >= iy0 && cur + 1 < iy1) VecIO<T>::store(out + (size_t)(cur + 1) * W * C, accB);
 }
 
 int launch_upsample2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
@@ -886,19 +934,23 @@ int launch_upsample2(Prec p, const void* src, const float* a, const float* b, vo
   FU_REQUIRE(outH >= 2 * H && outW >= 2 * W, "upsample: target smaller than 2x source");
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
   dim3 g; int CV; unsigned rcp;
-  if (p == PREC_F32) {
-    FU_REQUIRE(row_grid<float>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
-    hipLaunchKernelGGL(k_upsample2<float>, g, dim3(256), 0, s, (const float*)src, a, b, (float*)dst, H, W, C, outH, outW,
-                       py0, px0, t, CV, rcp);
-  } else if (p == PREC_BF16) {
-    FU_REQUIRE(row_grid<bf16_t>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
-    hipLaunchKernelGGL(k_upsample2<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)src, a, b, (bf16_t*)dst, H, W, C, outH,
-                       outW, py0, px0, t, CV, rcp);
-  } else {
-    FU_REQUIRE(row_grid<f16_t>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
-    hipLaunchKernelGGL(k_upsample2<f16_t>, g, dim3(256), 0, s, (const f16_t*)src, a, b, (f16_t*)dst, H, W, C, outH,
-                       outW, py0, px0, t, CV, rcp);
-  }
+  // four rows per thread where that still leaves >= 2048 workgroups, else one
+  auto go = [&](auto tag) {
+    using T = decltype(tag);
+    FU_REQUIRE(row_grid<T>(C, outW, outH, B, &g, &CV, &rcp), "upsample: unsupported shape (C=%d H=%d B=%d)", C, outH, B);
+    if ((int64_t)g.x * ceil_div(outH, 4) * B >= 2048) {
+      g.y = ceil_div(outH, 4);
+      hipLaunchKernelGGL((k_upsample2<T, 4>), g, dim3(256), 0, s, (const T*)src, a, b, (T*)dst, H, W, C, outH, outW, py0, px0,
+                         t, CV, rcp);
+    } else {
+      hipLaunchKernelGGL((k_upsample2<T, 1>), g, dim3(256), 0, s, (const T*)src, a, b, (T*)dst, H, W, C, outH, outW, py0, px0,
+                         t, CV, rcp);
+    }
+    return 0;
+  };
+  if (p == PREC_F32) FU_TRY(go(float{}));
+  else if (p == PREC_BF16) FU_TRY(go(bf16_t{}));
+  else FU_TRY(go(f16_t{}));
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -908,19 +960,30 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
   if (FU_EXP_SKIP(32)) return 0;
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
   dim3 g; int CV; unsigned rcp;
-  if (p == PREC_F32) {
-    FU_REQUIRE(row_grid<float>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_upsample2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C, outH,
-                       outW, py0, px0, t, CV, rcp);
-  } else if (p == PREC_BF16) {
-    FU_REQUIRE(row_grid<bf16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W, C, outH,
-                       outW, py0, px0, t, CV, rcp);
-  } else {
-    FU_REQUIRE(row_grid<f16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    hipLaunchKernelGGL(k_upsample2_bwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)g_dst, (f16_t*)g_src, H, W, C, outH,
-                       outW, py0, px0, t, CV, rcp);
-  }
+  // strips of 8 input rows where that still leaves >= 1024 workgroups, else 4 or 2 (each strip re-reads the one or two
+  // output rows it shares with its neighbours)
+  auto go = [&](auto tag) {
+    using T = decltype(tag);
+    FU_REQUIRE(row_grid<T>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    const int64_t per_row = (int64_t)g.x * B;
+    if (per_row * ceil_div(H, 8) >= 1024) {
+      g.y = ceil_div(H, 8);
+      hipLaunchKernelGGL((k_upsample2_bwd<T, 8>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
+                         px0, t, CV, rcp);
+    } else if (per_row * ceil_div(H, 4) >= 1024) {
+      g.y = ceil_div(H, 4);
+      hipLaunchKernelGGL((k_upsample2_bwd<T, 4>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
+                         px0, t, CV, rcp);
+    } else {
+      g.y = ceil_div(H, 2);
+      hipLaunchKernelGGL((k_upsample2_bwd<T, 2>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
+                         px0, t, CV, rcp);
+    }
+    return 0;
+  };
+  if (p == PREC_F32) FU_TRY(go(float{}));
+  else if (p == PREC_BF16) FU_TRY(go(bf16_t{}));
+  else FU_TRY(go(f16_t{}));
   FU_LAUNCH_CHECK();
   return 0;
 }
