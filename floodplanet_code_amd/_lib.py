@@ -92,6 +92,7 @@ SIGNATURES = {
     "fu_test_force_lockstep_wgrad": (None, [_i]),
     "fu_test_conv_tile_mode": (None, [_i]),
     "fu_test_bnb_separate": (None, [_i]),
+    "fu_test_head_store_g": (None, [_i]),
     "fu_test_force_full_taps": (None, [_i]),
     "fu_test_perturb_bnb_sums": (None, [_f]),
     "fu_test_get_buffer": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i64)]),

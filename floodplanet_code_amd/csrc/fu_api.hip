@@ -216,6 +216,7 @@ struct Conv {
   void* gy = nullptr;
   const void* pool_g = nullptr;   // backward: dL/d(maxpool(this output)), to be folded into this conv's BN backward
   int bnb_tiles = 0;              // backward: > 0 = the producer of gy left this many rows of BN-backward sums in bnb_part
+  HeadGrad head;                  // backward, last conv only: gy was not stored, the BN-backward apply recomputes it (dl != null)
 };
 
 enum BlockKind { BK_INC = 0, BK_DOWN = 1, BK_UP = 2 };
@@ -851,6 +852,7 @@ int forward_impl(fu_ctx* c, const float* x, const SrcList* srcs, int B, bool tra
 // testing hook (fu_test_bnb_separate) and A/B switch (environment FU_BNB_SEPARATE): 1 = BatchNorm-backward sums always by
 // their own reduce pass, never from the producer of the gradient (BnbFuse, fu_common.h)
 static int g_bnb_separate = getenv("FU_BNB_SEPARATE") != nullptr ? 1 : 0;
+static int g_head_store_g = getenv("FU_HEAD_STORE_G") != nullptr ? 1 : 0;   // testing hook / A-B (fu_test_head_store_g): the head backward stores its data gradient even where the apply pass could recompute it
 // testing hook (fu_test_perturb_bnb_sums): the fused sums are multiplied by this factor after the kernel that emitted
 // them -- the negative control of the parity tests (a wrong fused sum must make them fail); 1 = off, no launch
 static float g_test_perturb_bnb = 1.f;
@@ -880,9 +882,11 @@ int backward_conv(fu_ctx* c, int i, int j, int B, hipStream_t s) {
   float* dbp = (side && par) ? c->db_part2 : c->db_part;
   if (side && c->wg_pending[par]) FU_HIP_CHECK(hipStreamWaitEvent(s, c->ev_wg[par], 0));   // buffer free again
   FU_TRY(launch_bn_bwd(c->prec, v.gy, v.y, v.cout, npix, v.a, v.b, v.mean, v.invstd, P(c, v.p_g), G(c, v.p_g),
-                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s, v.pool_g, B, H, W, v.bnb_tiles));
+                       G(c, v.p_beta), c->bnb_part, v.coef, dbp, &ndb, c->dscratch, s, v.pool_g, B, H, W, v.bnb_tiles,
+                       v.head.dl ? &v.head : nullptr));
   v.pool_g = nullptr;
   v.bnb_tiles = 0;
+  v.head = HeadGrad{};
   // weight (and bias) gradient
   ConvIn in = conv_input(c, i, j);
   const double fl = 2.0 * 9 * v.cin_real * v.cout * (double)B * H * W;
@@ -989,11 +993,17 @@ int backward_block_impl(fu_ctx* c, int block, const float* dlogits_ext, hipStrea
     if (want) {
       fz.y = last.y; fz.a = last.a; fz.b = last.b; fz.mean = last.mean; fz.invstd = last.invstd;
       fz.part = c->bnb_part; fz.max_elems = c->bnb_cap; fz.tiles_out = &tiles;
+      // ... and then g = dl . w need not be stored at all: the apply pass of that BatchNorm recomputes it (HeadGrad)
+      fz.skip_g = last.cout % 8 == 0 && 2048 % last.cout == 0 && !g_head_store_g;
     }
     FU_TRY(launch_head_bwd(c->prec, dl, last.y, last.a, last.b, P(c, c->p_outw), f.base_channels, f.n_classes,
                            (int64_t)B * f.height * f.width, last.gy, c->hb_part, G(c, c->p_outw), G(c, c->p_outb), s,
                            want ? &fz : nullptr));
     last.bnb_tiles = tiles;
+    FU_REQUIRE(!(want && fz.skip_g) || tiles > 0, "head backward: the fused BatchNorm sums were refused (partials %lld floats)",
+               (long long)c->bnb_cap);
+    last.head = HeadGrad{};
+    if (want && fz.skip_g) { last.head.dl = dl; last.head.w = P(c, c->p_outw); last.head.ncls = f.n_classes; }
     FU_TRY(perturb_bnb(c->bnb_part, tiles, last.cout, s));
     return 0;
   }
@@ -1861,4 +1871,5 @@ int fu_test_get_buffer(fu_ctx* c, int block, int which, void** ptr, int64_t* ele
 }  // extern "C"
 
 extern "C" void fu_test_bnb_separate(int on) { g_bnb_separate = on ? 1 : 0; }
+extern "C" void fu_test_head_store_g(int on) { g_head_store_g = on ? 1 : 0; }
 extern "C" void fu_test_perturb_bnb_sums(float factor) { g_test_perturb_bnb = factor; }

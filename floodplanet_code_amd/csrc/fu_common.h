@@ -226,6 +226,15 @@ struct BnbFuse {
   float* part = nullptr;
   int64_t max_elems = 0;                   // capacity of part (floats)
   int* tiles_out = nullptr;
+  bool skip_g = false;                     // head backward only: g itself is not stored (HeadGrad below recomputes it)
+};
+// The head's data gradient g[p][c] = sum_k dl[p][k] w[k][c] is two or three FMAs per element: when the head backward has
+// left the BatchNorm-backward sums of g behind (BnbFuse), the apply pass of that BatchNorm recomputes g from dl and w
+// instead of reading a stored copy -- one 134 MB write and one 134 MB read less per step at the bench shape.
+struct HeadGrad {
+  const float* dl = nullptr;               // dL/dlogits, NHWC fp32 [npix][ncls]
+  const float* w = nullptr;                // head weight [ncls][C]
+  int ncls = 0;
 };
 // per-launch options of the conv / wgrad launchers (host side only; travels inside ConvIn)
 struct LaunchOpts {
@@ -340,7 +349,8 @@ int64_t bn_bwd_partial_elems(int C, int64_t npix);
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s, const void* g_pool = nullptr, int B = 0, int H = 0, int W = 0, int ext_partials = 0);
+                  hipStream_t s, const void* g_pool = nullptr, int B = 0, int H = 0, int W = 0, int ext_partials = 0,
+                  const HeadGrad* head = nullptr);
 
 int launch_maxpool2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
                     hipStream_t s);

@@ -509,6 +509,85 @@ __global__ void k_bn_bwd_apply(T* __restrict__ g, const T* __restrict__ y, int C
   }
 }
 
+template <int V>
+__device__ __forceinline__ void load_coef(const float* a, const float* b, int c0, float (&av)[V], float (&bv)[V]);
+// The same apply pass for the BatchNorm in front of the 1x1 head, with g = dl . w recomputed per element (HeadGrad,
+// fu_common.h) instead of read: g stays in fp32 (the stored copy was rounded to the element type), the sums in `coef`
+// were taken by k_head_bwd from the same fp32 values.  16-byte vectors, one pixel's channels on C / V lanes.
+template <typename T, int NC>
+__global__ __launch_bounds__(BNB_THREADS) void k_bn_bwd_apply_head(const float* __restrict__ dl, const float* __restrict__ w,
+                                                                    int ncls_rt, T* __restrict__ g, const T* __restrict__ y,
+                                                                    int C, int64_t npix, const float* __restrict__ a,
+                                                                    const float* __restrict__ b,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ coef,
+                                                                    float* __restrict__ db_partials) {
+  constexpr int V = VecIO<T>::V;
+  constexpr int KMAX = NC ? NC : HEAD_MAX_CLS;
+  const int ncls = NC ? NC : ncls_rt;
+  extern __shared__ float sm[];  // [rows][C]
+  const int CV = C / V;
+  const int rows = BNB_THREADS / CV;
+  const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+  float sd[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) sd[j] = 0.f;
+  if (row < rows) {
+    float av[V], bv[V], mv[V], iv[V], c1[V], c2[V], wv[KMAX][V];
+    load_coef<V>(a, b, cv * V, av, bv);
+    load_coef<V>(mean, invstd, cv * V, mv, iv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      c1[j] = coef[(cv * V + j) * 2 + 0];
+      c2[j] = coef[(cv * V + j) * 2 + 1];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) wv[k][j] = k < ncls ? w[k * C + cv * V + j] : 0.f;
+    }
+    constexpr int U = 2;                                         // pixels in flight per thread
+    const int64_t step = (int64_t)gridDim.x * rows;
+    for (int64_t p0 = (int64_t)blockIdx.x * rows + row; p0 < npix; p0 += U * step) {
+      float yv[U][V], d[U][KMAX];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * step;
+        const bool ok = p < npix;
+        VecIO<T>::load(y + (ok ? p : p0) * C + cv * V, yv[u]);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) d[u][k] = (ok && k < ncls) ? dl[p * ncls + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * step;
+        if (p < npix) {
+          float o[V];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            float gv = 0.f;                                      // same expression and order as k_head_bwd
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+              if (k < ncls) gv += d[u][k] * wv[k][j];
+            const float z = bn_act_pre(av[j], yv[u][j], bv[j]);
+            const float gm = z > 0.f ? gv : 0.f;
+            const float xh = (yv[u][j] - mv[j]) * iv[j];
+            o[j] = av[j] * (gm - c1[j] - xh * c2[j]);
+            sd[j] += o[j];
+          }
+          VecIO<T>::store(g + p * C + cv * V, o);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) sm[row * C + cv * V + j] = sd[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += BNB_THREADS) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += sm[r * C + c];
+    db_partials[(int64_t)blockIdx.x * C + c] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm + ReLU backward with the max-pool backward folded in (round 2).  For the four encoder outputs that feed a pool,
 // dL/d relu(bn(y)) = g (the skip gradient written by the decoder's dgrad) + the pooled gradient routed to the first argmax
@@ -642,8 +721,10 @@ static void launch_bn_bwd_pool_t(bool apply, int nb, size_t sh, hipStream_t s, v
 int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const float* a, const float* b,
                   const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                   float* partials, float* coef, float* db_partials, int* n_db_partials, double* dscratch,
-                  hipStream_t s, const void* g_pool, int B, int H, int W, int ext_partials) {
+                  hipStream_t s, const void* g_pool, int B, int H, int W, int ext_partials, const HeadGrad* head) {
   (void)gamma;
+  FU_REQUIRE(head == nullptr || (ext_partials > 0 && g_pool == nullptr && p != PREC_F32 && C % 8 == 0 && BNB_THREADS % (C / 8) == 0),
+             "bn_bwd: a recomputed head gradient needs the producer's sums, a 16-bit element type and C | 2048");
   FU_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: channels must be a multiple of 4 and <= 1024 (got %d)", C);
   // ext_partials > 0: `partials` already holds that many [C][2] rows of the two sums (written by the producer of g, see
   // BnbFuse in fu_common.h) -- the reduce pass is skipped, the apply pass keeps its own grid
@@ -694,6 +775,25 @@ int launch_bn_bwd(Prec p, void* g, const void* y, int C, int64_t npix, const flo
     if (p == PREC_F32) launch_bn_bwd_pool_t<float>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
     else if (p == PREC_BF16) launch_bn_bwd_pool_t<bf16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
     else launch_bn_bwd_pool_t<f16_t>(true, nb, sh2, s, g, y, g_pool, C, B, H, W, a, b, mean, invstd, coef, db_partials);
+  } else if (head) {
+    const size_t shh = (size_t)(BNB_THREADS / (C / 8)) * C * sizeof(float);
+#define FU_APPLY_HEAD(TT, NC) \
+    hipLaunchKernelGGL((k_bn_bwd_apply_head<TT, NC>), dim3(nb), dim3(BNB_THREADS), shh, s, head->dl, head->w, head->ncls, \
+                       (TT*)g, (const TT*)y, C, npix, a, b, mean, invstd, coef, db_partials)
+    if (p == PREC_BF16) {
+      switch (head->ncls) {
+        case 2: FU_APPLY_HEAD(bf16_t, 2); break;
+        case 3: FU_APPLY_HEAD(bf16_t, 3); break;
+        default: FU_APPLY_HEAD(bf16_t, 0); break;
+      }
+    } else {
+      switch (head->ncls) {
+        case 2: FU_APPLY_HEAD(f16_t, 2); break;
+        case 3: FU_APPLY_HEAD(f16_t, 3); break;
+        default: FU_APPLY_HEAD(f16_t, 0); break;
+      }
+    }
+#undef FU_APPLY_HEAD
   } else if (p == PREC_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(nb), dim3(BNB_THREADS), sh2, s, (float*)g, (const float*)y, C, npix,
                        a, b, mean, invstd, coef, db_partials);
@@ -861,13 +961,7 @@ __global__ __launch_bounds__(256) void k_upsample2(const T* __restrict__ src, co
   }
 }
 
-// Backward of the bilinear x2 resize as a walk down the output rows: a thread owns an input column (16 bytes of channels)
-// and a strip of TY input rows; for every output row that touches the strip it reduces the row's gradient along x with
-// the column's tap list (<= UP_BWD_MAX taps, held in registers) and adds the result to the one or two input rows the
-// output row interpolates between (y_i0 / y_i1 / y_w1, the forward tables; y_i0 never decreases, so two running
-// accumulators suffice).  Every output row is read once per strip (the first version gathered per input pixel: every output
-// row was read by each of the two or three input rows under it, from different workgroups).
-template <typename T, int TY>
+template <typename T>
 __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gdst, T* __restrict__ gsrc, int H, int W,
                                                        int C, int outH, int outW, int py0, int px0, UpTables t, int CV,
                                                        unsigned rcpCV) {
@@ -875,58 +969,35 @@ __global__ __launch_bounds__(256) void k_upsample2_bwd(const T* __restrict__ gds
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= W * CV) return;
   const int ix = fast_div(item, CV, rcpCV), cv = item - ix * CV;
-  const int iy0 = blockIdx.y * TY, iy1 = min(iy0 + TY, H), bb = blockIdx.z;
+  const int iy = blockIdx.y, bb = blockIdx.z;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const T* base = gdst + (size_t)bb * outH * outW * C + cv * V;
+  // the column list of this lane once, ahead of the row loop (it was re-read from the table inside it, a dependent load
+  // and a data-dependent break per tap); same taps in the same order, so the sums are unchanged
   int xo[UP_BWD_MAX];
   float xw[UP_BWD_MAX];
 #pragma unroll
   for (int jx = 0; jx < UP_BWD_MAX; ++jx) { xo[jx] = t.xb_o[ix * UP_BWD_MAX + jx]; xw[jx] = t.xb_w[ix * UP_BWD_MAX + jx]; }
-  // the output rows that touch the strip: the gather lists are in ascending order (block-uniform scalar loads)
-  const int lo = t.yb_o[iy0 * UP_BWD_MAX];
-  int hi = lo;
-#pragma unroll
-  for (int j = 0; j < UP_BWD_MAX; ++j) hi = max(hi, t.yb_o[(iy1 - 1) * UP_BWD_MAX + j]);
-  const T* base = gdst + ((size_t)bb * outH + py0) * outW * C + (size_t)px0 * C + cv * V;
-  T* out = gsrc + (size_t)bb * H * W * C + (size_t)ix * C + cv * V;
-  float accA[V], accB[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
-  int cur = t.y_i0[lo];
-  for (int uy = lo; uy <= hi; ++uy) {
-    const int a0 = t.y_i0[uy], a1 = t.y_i1[uy];
-    const float w1 = t.y_w1[uy];
-    while (cur < a0) {                                           // block-uniform
-      if (cur >= iy0 && cur < iy1) VecIO<T>::store(out + (size_t)cur * W * C, accA);
-#pragma unroll
-      for (int j = 0; j < V; ++j) { accA[j] = accB[j]; accB[j] = 0.f; }
-      ++cur;
-    }
-    const T* rowp = base + (size_t)uy * outW * C;
-    float gv[UP_BWD_MAX][V];
+  for (int jy = 0; jy < UP_BWD_MAX; ++jy) {
+    const int oy = t.yb_o[iy * UP_BWD_MAX + jy];                // block-uniform
+    if (oy < 0) break;
+    const float wy = t.yb_w[iy * UP_BWD_MAX + jy];
+    const T* rowp = base + (size_t)(oy + py0) * outW * C;
 #pragma unroll
     for (int jx = 0; jx < UP_BWD_MAX; ++jx) {
-      if (xo[jx] >= 0) VecIO<T>::load(rowp + (size_t)xo[jx] * C, gv[jx]);
-      else {
+      if (__builtin_amdgcn_ballot_w64(xo[jx] >= 0) == 0) break;  // wave-uniform: lists are filled front to back
+      if (xo[jx] >= 0) {
+        const float w = wy * xw[jx];
+        float gv[V];
+        VecIO<T>::load(rowp + (size_t)(xo[jx] + px0) * C, gv);
 #pragma unroll
-        for (int j = 0; j < V; ++j) gv[jx][j] = 0.f;
+        for (int j = 0; j < V; ++j) acc[j] += w * gv[j];
       }
     }
-    float r[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      r[j] = xw[0] * gv[0][j];
-#pragma unroll
-      for (int jx = 1; jx < UP_BWD_MAX; ++jx) r[j] += xw[jx] * gv[jx][j];
-    }
-    const float w0 = 1.f - w1;
-    const bool same = a1 == cur;                                 // the last input row: both taps are that row
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      accA[j] += w0 * r[j];
-      if (same) accA[j] += w1 * r[j]; else accB[j] += w1 * r[j];
-    }
   }
-  if (cur >= iy0 && cur < iy1) VecIO<T>::store(out + (size_t)cur * W * C, accA);
-  if (cur + 1 >= iy0 && cur + 1 < iy1) VecIO<T>::store(out + (size_t)(cur + 1) * W * C, accB);
+  VecIO<T>::store(gsrc + ((size_t)(bb * H + iy) * W + ix) * C + cv * V, acc);
 }
 
 int launch_upsample2(Prec p, const void* src, const float* a, const float* b, void* dst, int B, int H, int W, int C,
@@ -960,30 +1031,19 @@ int launch_upsample2_bwd(Prec p, const void* g_dst, void* g_src, int B, int H, i
   if (FU_EXP_SKIP(32)) return 0;
   const int py0 = (outH - 2 * H) / 2, px0 = (outW - 2 * W) / 2;
   dim3 g; int CV; unsigned rcp;
-  // strips of 8 input rows where that still leaves >= 1024 workgroups, else 4 or 2 (each strip re-reads the one or two
-  // output rows it shares with its neighbours)
-  auto go = [&](auto tag) {
-    using T = decltype(tag);
-    FU_REQUIRE(row_grid<T>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
-    const int64_t per_row = (int64_t)g.x * B;
-    if (per_row * ceil_div(H, 8) >= 1024) {
-      g.y = ceil_div(H, 8);
-      hipLaunchKernelGGL((k_upsample2_bwd<T, 8>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
-                         px0, t, CV, rcp);
-    } else if (per_row * ceil_div(H, 4) >= 1024) {
-      g.y = ceil_div(H, 4);
-      hipLaunchKernelGGL((k_upsample2_bwd<T, 4>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
-                         px0, t, CV, rcp);
-    } else {
-      g.y = ceil_div(H, 2);
-      hipLaunchKernelGGL((k_upsample2_bwd<T, 2>), g, dim3(256), 0, s, (const T*)g_dst, (T*)g_src, H, W, C, outH, outW, py0,
-                         px0, t, CV, rcp);
-    }
-    return 0;
-  };
-  if (p == PREC_F32) FU_TRY(go(float{}));
-  else if (p == PREC_BF16) FU_TRY(go(bf16_t{}));
-  else FU_TRY(go(f16_t{}));
+  if (p == PREC_F32) {
+    FU_REQUIRE(row_grid<float>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<float>, g, dim3(256), 0, s, (const float*)g_dst, (float*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  } else if (p == PREC_BF16) {
+    FU_REQUIRE(row_grid<bf16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<bf16_t>, g, dim3(256), 0, s, (const bf16_t*)g_dst, (bf16_t*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  } else {
+    FU_REQUIRE(row_grid<f16_t>(C, W, H, B, &g, &CV, &rcp), "upsample_bwd: unsupported shape (C=%d H=%d B=%d)", C, H, B);
+    hipLaunchKernelGGL(k_upsample2_bwd<f16_t>, g, dim3(256), 0, s, (const f16_t*)g_dst, (f16_t*)g_src, H, W, C, outH,
+                       outW, py0, px0, t, CV, rcp);
+  }
   FU_LAUNCH_CHECK();
   return 0;
 }
@@ -1658,7 +1718,7 @@ static constexpr int HB_BLOCKS = 2048;
 
 // BNB: also emit the BatchNorm-backward sums of g (sum g*m, sum g*m*xhat per channel, BnbFuse in fu_common.h) -- y and the
 // mask are in registers here anyway; bnpart[block][C][2], one row per block.
-template <typename T, int NC, int U, bool BNB>
+template <typename T, int NC, int U, bool BNB, bool STORE = true>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, const T* __restrict__ y,
                                                   const float* __restrict__ a, const float* __restrict__ b,
                                                   const float* __restrict__ w, int C, int ncls_rt, int npix, int LPP,
@@ -1729,7 +1789,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dl, 
             db[k] += d[u][k];
           }
         }
-        VecIO<T>::store(g + (size_t)p * C + lane_in * V, o);
+        if constexpr (STORE) VecIO<T>::store(g + (size_t)p * C + lane_in * V, o);
         if constexpr (BNB) {
 #pragma unroll
           for (int j = 0; j < V; ++j) {
@@ -1816,7 +1876,10 @@ int launch_head_bwd(Prec p, const float* dlogits_nhwc, const void* y, const floa
   float* bpart = bnb ? fuse->part : nullptr;
 #define FU_HEAD_BWD(TT, NC)                                                                                     \
   do {                                                                                                          \
-    if (bnb)                                                                                                    \
+    if (bnb && fuse->skip_g)                                                                                    \
+      hipLaunchKernelGGL((k_head_bwd<TT, NC, U, true, false>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, \
+                         w, C, ncls, (int)npix, LPP, (TT*)g, partials, bmean, binv, bpart);                     \
+    else if (bnb)                                                                                               \
       hipLaunchKernelGGL((k_head_bwd<TT, NC, U, true>), dim3(nblk), dim3(256), sh, s, dlogits_nhwc, (const TT*)y, a, b, w, C, \
                          ncls, (int)npix, LPP, (TT*)g, partials, bmean, binv, bpart);                           \
     else                                                                                                        \

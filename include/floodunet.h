@@ -299,6 +299,9 @@ void fu_test_conv_tile_mode(int mode);
  * modes take them from the kernel that produces the gradient where it can (row-stationary dgrad, head backward).
  * Process-wide. */
 void fu_test_bnb_separate(int on);
+/* Testing hook: on != 0 makes the head backward store its data gradient g = dlogits . W even where (16-bit modes, fused
+ * sums) the BatchNorm-backward apply pass of the last conv would recompute it from dlogits and W.  Process-wide. */
+void fu_test_head_store_g(int on);
 /* Testing hook: on != 0 runs the late-fusion 1x1 convs (weights embedded as the centre tap of a 3x3) through all nine taps
  * instead of the 1-tap instantiation of the fast kernel; the other eight taps multiply exact zeros, so the results are
  * bit-identical.  Process-wide. */

@@ -413,6 +413,58 @@ def test_every_backward_block_default_dispatch_equals_conservative_dispatch(prec
     assert worst[0] > 0.0            # the two dispatches really are different code
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_head_gradient_recomputed_in_the_apply_pass_equals_the_stored_one(prec):
+    """Bench shape.  By default the head backward does not store g = dlogits . W: the BatchNorm-backward apply pass of the
+    last conv recomputes it in fp32 (k_bn_bwd_apply_head).  With fu_test_head_store_g(1) the head backward stores g in the
+    element type and the plain apply pass reads it.  The head's own gradients are bit-identical (same kernel arithmetic),
+    block up4's parameter gradients and outgoing gradient maps agree to the element type's rounding."""
+    from oracle import unet_oracle as O
+    lib = _lib.load()
+    torch.manual_seed(0)
+    net = HipUNet(8, 3, precision=prec).to(DEV).train()
+    batch = O.make_batch(16, 8, 256, 256, seed=11)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    dt = LOWP[prec]["dt"]
+    res = []
+    for store in (0, 1):
+        net._forward_raw(x, True, want_logits=False)
+        net._loss_raw(t, 0, DEV)
+        s = net._stream(DEV)
+        try:
+            lib.fu_test_head_store_g(store)
+            check(lib.fu_backward_block(net._ctx, 0, None, s))
+            check(lib.fu_backward_block(net._ctx, 1, None, s))
+        finally:
+            lib.fu_test_head_store_g(0)
+        torch.cuda.synchronize()
+        grads = {}
+        for b in (0, 1):
+            o, n = C.c_int64(), C.c_int64()
+            check(lib.fu_block_param_range(net._ctx, b, C.byref(o), C.byref(n)))
+            grads.update({k: net.flat_grads()[off:off + m].clone() for (k, p, off, m) in net._table
+                          if o.value <= off < o.value + n.value})
+        res.append((grads, _outgoing(net, 8, dt)))
+    (g_re, out_re), (g_st, out_st) = res
+    tol = 2.0 ** -7 if prec == "bf16" else 2.0 ** -10
+    worst = 0.0
+    for k in g_re:
+        if k.startswith("outc."):
+            assert torch.equal(g_re[k], g_st[k]), k
+            continue
+        if is_dead_bias(k) or g_st[k].norm().item() < 1e-9:
+            continue
+        e = rel(g_re[k], g_st[k])
+        worst = max(worst, e)
+        assert e <= tol, (k, e)
+    for (label, a), (_, c) in zip(out_re, out_st):
+        e = rel(a.float(), c.float())
+        worst = max(worst, e)
+        assert e <= tol, (label, e)
+    print(f"{prec}: recomputed vs stored head gradient, worst deviation {worst:.3e}; bound {tol:.3e}")
+    assert worst > 0.0               # the two routes really are different code
+
+
 def test_negative_control_perturbed_fused_sums_fail_the_block_check():
     """The per-block check can fail: fused sums x 1.1 inside block 2 (up3) move that block's first BatchNorm's gradients by
     10 % (bound of the real check: 2^-7)."""
