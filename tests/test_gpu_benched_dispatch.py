@@ -413,6 +413,36 @@ def test_every_backward_block_default_dispatch_equals_conservative_dispatch(prec
     assert worst[0] > 0.0            # the two dispatches really are different code
 
 
+def test_backward_blocks_at_the_largest_benched_shape_default_equals_conservative():
+    """BASELINE configs[3]'s shape at its batch (9 bands = image + DEM side by side, 512x512, B=16, fp16): the largest grids
+    the bench launches (8192-workgroup conv launches, 4 M pixels per map).  Same per-block check as above on the first and
+    the last decoder block, the deepest encoder block and the stem: an index that overflows or a tile decode that wraps at
+    this size shows up as a gradient far outside the rounding bound."""
+    from oracle import unet_oracle as O
+    torch.manual_seed(0)
+    net = HipUNet(9, 2, precision="fp16").to(DEV).train()
+    batch = O.make_batch(16, 9, 512, 512, seed=5)
+    x, t = batch["image"].to(DEV), batch["target"].to(DEV)
+    tol = 2.0 ** -10
+    worst = (0.0, None)
+    for b in (1, 4, 5, 9):
+        g_def, out_def = _run_block(net, x, t, b, conservative=False)
+        g_con, out_con = _run_block(net, x, t, b, conservative=True)
+        for k in g_def:
+            if is_dead_bias(k) or g_con[k].norm().item() < 1e-9:
+                continue
+            assert torch.isfinite(g_def[k]).all(), k
+            e = rel(g_def[k], g_con[k])
+            worst = max(worst, (e, k))
+            assert e <= tol, (b, k, e)
+        for (label, a), (_, c) in zip(out_def, out_con):
+            e = rel(a.float(), c.float())
+            worst = max(worst, (e, f"block {b}: {label}"))
+            assert e <= tol, (b, label, e)
+    print(f"512x512 B=16 fp16: worst per-block default-vs-conservative deviation {worst[0]:.3e} ({worst[1]}); bound {tol:.3e}")
+    assert worst[0] > 0.0
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_head_gradient_recomputed_in_the_apply_pass_equals_the_stored_one(prec):
     """Bench shape.  By default the head backward does not store g = dlogits . W: the BatchNorm-backward apply pass of the
