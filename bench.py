@@ -591,7 +591,10 @@ def main():
         cfg["world_size_seen"] = dist.get_world_size()
         cfg["devices_visible"] = n_dev
         cfg["backward_chain"] = {0: "serial (one stream)", 1: "side stream, join per block",
-                                 2: "side stream, join per all-reduce bucket"}[trainer._side_mode()]
+                                 2: ("side stream; per all-reduce bucket the stream the collective is launched from waits "
+                                     "for both backward chains (fu_backward_fence), the compute stream joins once, after the "
+                                     "last block" if os.environ.get("FU_DP_JOIN_AT_BUCKETS") != "1" else
+                                     "side stream, compute stream joined per all-reduce bucket")}[trainer._side_mode()]
         if os.environ.get("FU_DP_SIDE_MODE") is not None:
             cfg["backward_chain_forced_by_env"] = "FU_DP_SIDE_MODE=" + os.environ["FU_DP_SIDE_MODE"]
         red = getattr(trainer, "_reducer", None)

@@ -98,6 +98,7 @@ SIGNATURES = {
     "fu_test_get_buffer": (_i, [_p, _i, _i, C.POINTER(_p), C.POINTER(_i64)]),
     "fu_set_side_stream": (_i, [_p, _i]),
     "fu_backward_join": (_i, [_p, _p]),
+    "fu_backward_fence": (_i, [_p, _p, _p]),
     "fu_dp_unique_id": (_i, [_p]),
     "fu_dp_init": (_i, [_p, _p, _i, _i]),
     "fu_dp_broadcast_state": (_i, [_p, _p]),

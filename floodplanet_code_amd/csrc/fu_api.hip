@@ -339,6 +339,7 @@ struct fu_ctx {
                                   //     5.66 -> 5.64 ms per step and 0.338 -> 0.350 of peak for the conv launches in the step)
   hipStream_t side_def = nullptr; // ... the default priority (mode 2: an all-reduce bucket waits for its weight gradients)
   hipEvent_t ev_gy = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_blk = nullptr;
+  hipEvent_t ev_fence[2] = {nullptr, nullptr};   // fu_backward_fence: compute stream / side stream (created on first use)
   int wg_parity = 0;
   int side_mode = 1;              // fu_set_side_stream: 0 off, 1 on (blocks join), 2 on (the caller joins: fu_backward_join)
   bool wg_pending[2] = {false, false};
@@ -1149,7 +1150,7 @@ int fu_destroy(fu_ctx* c) {
   if (c->side) {
     if (c->side_lo) (void)hipStreamDestroy(c->side_lo);
     if (c->side_def) (void)hipStreamDestroy(c->side_def);
-    for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk, c->ev_fence[0], c->ev_fence[1]}) if (e) (void)hipEventDestroy(e);
   }
   if (c->arena.base) (void)hipFree(c->arena.base);
   for (void* p : c->extra_allocs) (void)hipFree(p);
@@ -1323,6 +1324,20 @@ int fu_backward_join(fu_ctx* c, fu_stream stream) {
     FU_HIP_CHECK(hipEventRecord(c->ev_blk, c->side));
     FU_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, c->ev_blk, 0));
     c->wg_pending[0] = c->wg_pending[1] = false;
+  }
+  return FU_OK;
+}
+
+int fu_backward_fence(fu_ctx* c, fu_stream stream, fu_stream waiter) {
+  FU_REQUIRE(c, "null context");
+  FU_REQUIRE(stream != waiter, "fu_backward_fence: the waiting stream must not be the compute stream (use fu_backward_join)");
+  if (!c->ev_fence[0]) FU_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fence[0], hipEventDisableTiming));
+  if (!c->ev_fence[1]) FU_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fence[1], hipEventDisableTiming));
+  FU_HIP_CHECK(hipEventRecord(c->ev_fence[0], (hipStream_t)stream));
+  FU_HIP_CHECK(hipStreamWaitEvent((hipStream_t)waiter, c->ev_fence[0], 0));
+  if (c->side && c->side_mode != 0) {     // (nothing is pending there in mode 1: every block has joined already)
+    FU_HIP_CHECK(hipEventRecord(c->ev_fence[1], c->side));
+    FU_HIP_CHECK(hipStreamWaitEvent((hipStream_t)waiter, c->ev_fence[1], 0));
   }
   return FU_OK;
 }
@@ -1526,7 +1541,7 @@ struct Dp {
   void* lib = nullptr;
   void* comm = nullptr;
   hipStream_t stream = nullptr;       // communication stream: all-reduces run here, beside the backward kernels
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_side = nullptr;
   int rank = 0, world = 1;
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, fu_dp_id, int) = nullptr;
@@ -1592,7 +1607,8 @@ int fu_dp_init(fu_ctx* c, const fu_dp_id* id, int rank, int world) {
   }
   if (st == 0 && (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
                   hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
-                  hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess)) {
+                  hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&d->ev_side, hipEventDisableTiming) != hipSuccess)) {
     set_error("fu_dp_init: stream / event creation failed");
     st = FU_ERR_HIP;
   }
@@ -1613,6 +1629,7 @@ int fu_dp_destroy(fu_ctx* c) {
   if (d->comm) (void)d->CommDestroy(d->comm);
   if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
   if (d->ev_done) (void)hipEventDestroy(d->ev_done);
+  if (d->ev_side) (void)hipEventDestroy(d->ev_side);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
   c->dp = nullptr;
@@ -1644,6 +1661,10 @@ int fu_allreduce_begin(fu_ctx* c, int64_t flat_offset, int64_t numel, fu_stream 
   // fu_backward_block); the all-reduce starts behind them on the communication stream, the caller's stream moves on
   FU_HIP_CHECK(hipEventRecord(d->ev_ready, (hipStream_t)stream));
   FU_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_ready, 0));
+  if (c->side && c->side_mode == 2) {      // caller-join mode: the weight-gradient chain may still be behind; only the
+    FU_HIP_CHECK(hipEventRecord(d->ev_side, c->side));             // communication stream waits for it, `stream` moves on
+    FU_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ev_side, 0));
+  }
   float* g = c->G + flat_offset;
   FU_NCCL(d, d->AllReduce(g, g, (size_t)numel, kNcclFloat32, kNcclSum, d->comm, d->stream));
   return FU_OK;

@@ -70,14 +70,20 @@ class BucketedReducer:
     def bucket_bytes(self, elem_bytes: int = 4) -> List[int]:
         return [n * elem_bytes for _, _, n in self.buckets]
 
-    def block_done(self, flat_grad: torch.Tensor, block: int) -> None:
+    def block_done(self, flat_grad: torch.Tensor, block: int, launch_stream=None) -> None:
         if self.world_size <= 1 or block not in self._by_last:
             return
         off, n = self._by_last[block]
         # all_reduce(async_op=True) orders itself after the work already enqueued on the current stream and
-        # runs on the process group's own stream: the next backward blocks overlap with it.
-        self._pending.append(dist.all_reduce(flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+        # runs on the process group's own stream: the next backward blocks overlap with it.  launch_stream: the stream
+        # that is "current" for the call -- one that waits for the bucket's gradients (fu_backward_fence) while the compute
+        # stream does not.
+        if launch_stream is not None:
+            with torch.cuda.stream(launch_stream):
+                w = dist.all_reduce(flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(w)
 
     def finish(self) -> None:
         timed = self.timing and self._pending and torch.cuda.is_available()
@@ -135,6 +141,7 @@ class DataParallelTrainer:
         self._gx = self._gt = self._gloss = self._gscal = self._gscal_host = None
         self._g_ignore = None
         self._reducer: Optional[BucketedReducer] = None
+        self._launch_stream = None     # the stream the bucket all-reduces are launched from (mode 2, fu_backward_fence)
         self._synced = False
 
     def _side_mode(self) -> int:
@@ -230,11 +237,26 @@ class DataParallelTrainer:
             # other backend gets the serial chain (mode 0).
             _lib.check(lib.fu_set_side_stream(net._ctx, self._side_mode()))
             nb = lib.fu_num_blocks(net._ctx)
+            # Mode 2 (RCCL): at a bucket's end only the stream the all-reduce is launched from waits for the two backward
+            # chains (fu_backward_fence); the compute stream goes straight on with the next block.  Joining the compute
+            # stream there instead made it stand still until the weight-gradient chain had caught up, four times per step:
+            # 5.63 against 5.45 ms per step in one process without any collective (tools/r3_blocks.sh).  The last block
+            # joins: the optimizer step reads every gradient on the compute stream.
+            fenced = self._side_mode() == 2 and x.is_cuda and os.environ.get("FU_DP_JOIN_AT_BUCKETS") != "1"
+            if fenced and self._launch_stream is None:
+                self._launch_stream = torch.cuda.Stream(device=x.device)
             for b in range(nb):
                 _lib.check(lib.fu_backward_block(net._ctx, b, None, stream))
-                if b in self._reducer._by_last or b == nb - 1:
+                if b == nb - 1:
                     _lib.check(lib.fu_backward_join(net._ctx, stream))
-                self._reducer.block_done(flat, b)
+                    self._reducer.block_done(flat, b)
+                elif b in self._reducer._by_last:
+                    if fenced:
+                        _lib.check(lib.fu_backward_fence(net._ctx, stream, self._launch_stream.cuda_stream))
+                        self._reducer.block_done(flat, b, self._launch_stream)
+                    else:
+                        _lib.check(lib.fu_backward_join(net._ctx, stream))
+                        self._reducer.block_done(flat, b)
             _lib.check(lib.fu_set_side_stream(net._ctx, 1))
             self._reducer.finish()
         self.step_count += 1

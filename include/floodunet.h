@@ -165,6 +165,12 @@ int fu_set_side_stream(fu_ctx* ctx, int mode);
  * factor is dropped by the next fu_forward / fu_loss_* call. */
 int fu_scale_loss_grad(fu_ctx* ctx, const float* scale_dev, fu_stream stream);
 int fu_backward_join(fu_ctx* ctx, fu_stream stream);
+/* Mode 2, without stalling the compute stream: `waiter` (any other stream, e.g. the one a collective is launched from) waits
+ * for every gradient-producing launch enqueued so far -- the work on `stream` and the weight-gradient chain on the side
+ * stream.  Neither `stream` nor the side stream waits for anything: the backward blocks that follow start at once, the
+ * bucket's all-reduce starts when both chains have reached this point.  (fu_allreduce_begin does the same internally.)
+ * The last bucket still needs fu_backward_join before the optimizer step reads the gradients on `stream`. */
+int fu_backward_fence(fu_ctx* ctx, fu_stream stream, fu_stream waiter);
 
 /* The same, one block at a time in backward order: block 0 = outc, 1..4 = up4..up1, 5..8 = down4..down1,
  * 9 = inc.  After block k returns, the gradient range fu_block_param_range(k) is final on `stream`. */
@@ -219,8 +225,9 @@ int64_t fu_exact_sync_bytes(const fu_ctx* ctx);
  * else in the library depends on it.  One communicator per context.  The semantics are DESIGN.md section 6's: every rank
  * runs the step on its own tiles; per backward bucket (a contiguous range of the flat gradient buffer,
  * fu_block_param_range) fu_allreduce_begin starts a SUM all-reduce on the context's communication stream, ordered behind
- * the work enqueued on `stream` so far (the bucket's gradients must be final there: fu_backward_block in side-stream mode
- * 0 / 1, or fu_backward_join in mode 2), while the remaining backward blocks keep `stream` busy; fu_allreduce_wait makes
+ * the work enqueued on `stream` so far and, in side-stream mode 2, behind the weight-gradient chain enqueued so far (the
+ * communication stream waits for both; `stream` is not joined: call fu_backward_join once, after the last block, before the
+ * optimizer step), while the remaining backward blocks keep `stream` busy; fu_allreduce_wait makes
  * `stream` wait for every all-reduce begun so far; then fu_adam_step(..., grad_scale = 1 / world, ...).
  *   rank 0: fu_dp_unique_id(&id); ship the 128 bytes to the other ranks by any means (file, socket, MPI, environment);
  *   every rank: fu_dp_init(ctx, &id, rank, world); fu_dp_broadcast_state(ctx, stream) once (rank 0's parameters and

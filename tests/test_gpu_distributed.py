@@ -291,7 +291,10 @@ def _cabi_dp_steps(net, x, t, world_scale):
         for b in range(nb):
             _lib.check(lib.fu_backward_block(net._ctx, b, None, s))
             if b in by_last:
-                _lib.check(lib.fu_backward_join(net._ctx, s))
+                # only the last bucket joins the compute stream (the optimizer reads the gradients there); for the others
+                # fu_allreduce_begin orders the collective behind both backward chains by itself
+                if b == nb - 1:
+                    _lib.check(lib.fu_backward_join(net._ctx, s))
                 _lib.check(lib.fu_allreduce_begin(net._ctx, by_last[b][0], by_last[b][1], s))
         _lib.check(lib.fu_set_side_stream(net._ctx, 1))
         _lib.check(lib.fu_allreduce_wait(net._ctx, s))
