@@ -31,6 +31,8 @@
 #define launch_conv3x3_rs launch_conv3x3_rs_f16
 #define conv3x3_c8_eligible conv3x3_c8_eligible_f16
 #define launch_conv3x3_c8 launch_conv3x3_c8_f16
+#define conv3x3_pp_eligible conv3x3_pp_eligible_f16
+#define launch_conv3x3_pp launch_conv3x3_pp_f16
 #endif
 
 #include <type_traits>
@@ -135,6 +137,7 @@ struct BConvP {
   // row-stationary kernel, dgrad into a BatchNorm's output gradient (BnbFuse, fu_common.h): the raw conv output y of that
   // BatchNorm, its a / b / mean / invstd, and the per-tile sums [nPix][N][2]; all null otherwise
   const bf16_t* bnb_y; const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_invstd; float* bnb_part;
+  int nTiles;                // persistent ping-pong kernel (fu_conv_pp.hip): nPix * nCo, walked by gridDim.x workgroups
 };
 
 // aligned-shape fast path (fu_conv_bf16_fast.hip)
@@ -146,6 +149,9 @@ int launch_conv3x3_c8(BConvP& P, const LaunchOpts& o, hipStream_t s);
 // row-stationary 16x16x32 kernel (fu_conv_rs.hip)
 bool conv3x3_rs_eligible(const BConvP& P);
 int launch_conv3x3_rs(BConvP& P, const LaunchOpts& o, hipStream_t s);
+// persistent ping-pong row-stationary kernel (fu_conv_pp.hip): 8 waves, two LDS stages, one workgroup per CU
+bool conv3x3_pp_eligible(const BConvP& P);
+int launch_conv3x3_pp(BConvP& P, const LaunchOpts& o, hipStream_t s);
 
 }  // namespace fu
 

@@ -574,6 +574,8 @@ int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   // workgroups.  Measured per layer against the kernels below (bench shapes, forward, tools/conv_modes.py): 5-11 % faster
   // on the 128x128, 64x64 and 32x32 layers with N >= 512 channels x tiles, equal on the two-chunk 256x256 layers, slower
   // below 512 workgroups (16x16 level, 512 -> 256 at 32x32).  Tile mode 3 forces it, modes 1 / 2 exclude it.
+  // persistent ping-pong kernel (fu_conv_pp.hip): tile mode 4 forces it
+  if (g_bf16_tile_mode == 4 && conv3x3_pp_eligible(P)) return launch_conv3x3_pp(P, o, s);
   if (conv3x3_rs_eligible(P)) {
     const int64_t t256 = (int64_t)P.B * (P.H / 16) * (P.W / 16) * (P.N / 64);
     if (g_bf16_tile_mode == 3 || (g_bf16_tile_mode == 0 && t256 >= 512)) return launch_conv3x3_rs(P, o, s);
