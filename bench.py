@@ -583,6 +583,10 @@ def main():
            "train_gflop_per_tile": round(train_fl / 1e9, 3),
            "path": ("C ABI: DataParallelTrainer.step" if args.path == "cabi" else
                     "plugin: build_model('ms_model').training_step + loss.backward() + configure_optimizers().step()")}
+    # every FU_* variable of this process's environment: several of them switch the dispatch of the library that is being timed
+    # (FU_CONV_PP, FU_BNB_SEPARATE, FU_WGRAD_MODE, FU_NO_SIDE_STREAM, FU_LIB_PATH ...), and a line that does not name them cannot
+    # be compared with another
+    cfg["env_FU"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("FU_")}
     if world > 1:
         # what actually ran, for whoever reads an N > 1 record later: the world torch.distributed reports after
         # init_process_group (not the flag), the transport, the bucket plan and how long the compute stream stood still

@@ -33,6 +33,8 @@
 #define launch_conv3x3_c8 launch_conv3x3_c8_f16
 #define conv3x3_pp_eligible conv3x3_pp_eligible_f16
 #define launch_conv3x3_pp launch_conv3x3_pp_f16
+#define conv3x3_pp_preferred conv3x3_pp_preferred_f16
+#define conv3x3_pp_preferred_bnb conv3x3_pp_preferred_bnb_f16
 #endif
 
 #include <type_traits>
@@ -151,6 +153,8 @@ bool conv3x3_rs_eligible(const BConvP& P);
 int launch_conv3x3_rs(BConvP& P, const LaunchOpts& o, hipStream_t s);
 // persistent ping-pong row-stationary kernel (fu_conv_pp.hip): 8 waves, two LDS stages, one workgroup per CU
 bool conv3x3_pp_eligible(const BConvP& P);
+bool conv3x3_pp_preferred(const BConvP& P);   // ... and worth it: at least one tile per CU
+bool conv3x3_pp_preferred_bnb(const BConvP& P);   // ... when the launch is asked for fused BatchNorm-backward sums
 int launch_conv3x3_pp(BConvP& P, const LaunchOpts& o, hipStream_t s);
 
 }  // namespace fu

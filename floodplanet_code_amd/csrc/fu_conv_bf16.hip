@@ -1026,6 +1026,14 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   bf16_t* const sbuf0 = grp ? buf0 : buf1;       // where this wave stages while it multiplies an even stage: stage n+1+grp
   bf16_t* const sbuf1 = grp ? buf1 : buf0;
   mfma_prefetch(std::integral_constant<int, 0>{});
+  // Barrier of the loop: this wave's LDS traffic done (lgkmcnt), then s_barrier.  __syncthreads() also waits with vmcnt(0),
+  // i.e. for the loads of stage n+2 that the staging half has just issued -- they are needed one whole interval later (round 4:
+  // found with the persistent conv kernel, fu_conv_pp.hip; here the staging interval ended with an HBM latency in it).
+#ifdef FU_WGRAD_OLD_BARRIER     // (A/B builds)
+  auto wg_barrier = []() __attribute__((always_inline)) { __syncthreads(); };
+#else
+  auto wg_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
   auto body = [&](auto Par, int n) __attribute__((always_inline)) {
     constexpr int par = decltype(Par)::value;
 #ifdef FU_CONV_STAMPS
@@ -1035,7 +1043,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
 #ifdef FU_CONV_STAMPS
     const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();
+    wg_barrier();
 #ifdef FU_CONV_STAMPS
     const unsigned long long s2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1055,7 +1063,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
 #ifdef FU_CONV_STAMPS
     const unsigned long long s4 = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();
+    wg_barrier();
 #ifdef FU_CONV_STAMPS
     const unsigned long long s5 = __builtin_amdgcn_s_memtime();
     if (n > 0) { tM += s1 - s0; tB1 += s2 - s1; tSt += s3 - s2; tLd += s4 - s3; tB2 += s5 - s4; tGap += s0 - sPrev; }
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
     if (n + 1 >= T) break;
     body(std::integral_constant<int, 1>{}, n + 1);
   }
-  if (!grp) __syncthreads();                     // group 1's pre-loop barrier
+  if (!grp) wg_barrier();                        // group 1's pre-loop barrier
 #ifdef FU_CONV_STAMPS
   if (P.dbg && lane == 0 && blockIdx.x < 256) {
     unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;

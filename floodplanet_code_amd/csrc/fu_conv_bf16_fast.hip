@@ -14,6 +14,7 @@
 // Shapes it takes (conv3x3_bf16_fast_eligible): a second source only if C0 % 32 == 0, a second destination only if
 // D0 % BN == 0, every tensor < 2 GiB.  Everything else (and only that) runs on the general kernel.
 #include "fu_conv_bf16.h"
+#include <stdlib.h>
 
 #ifndef FU_FAST_LOADS_PER_STEP
 #define FU_FAST_LOADS_PER_STEP 2   // the next chunk's 15 global loads go out 2 per k-step behind that step's MFMAs: as one
@@ -574,8 +575,15 @@ int launch_conv3x3_bf16_fast(BConvP& P, const LaunchOpts& o, hipStream_t s) {
   // workgroups.  Measured per layer against the kernels below (bench shapes, forward, tools/conv_modes.py): 5-11 % faster
   // on the 128x128, 64x64 and 32x32 layers with N >= 512 channels x tiles, equal on the two-chunk 256x256 layers, slower
   // below 512 workgroups (16x16 level, 512 -> 256 at 32x32).  Tile mode 3 forces it, modes 1 / 2 exclude it.
-  // persistent ping-pong kernel (fu_conv_pp.hip): tile mode 4 forces it
-  if (g_bf16_tile_mode == 4 && conv3x3_pp_eligible(P)) return launch_conv3x3_pp(P, o, s);
+  // persistent ping-pong kernel (fu_conv_pp.hip): tile mode 4 forces it; by default wherever it is eligible (FU_CONV_PP=0: never,
+  // for A/B runs -- bench.py records every FU_* variable of its environment in the line it prints)
+  if (conv3x3_pp_eligible(P)) {
+    static const int pp_default = [] { const char* e = getenv("FU_CONV_PP"); return e ? atoi(e) : 1; }();
+    const bool wants_bnb = o.bnb != nullptr && o.bnb->y != nullptr && P.a0 == nullptr && P.dst1 == nullptr && P.stats == nullptr;
+    if (g_bf16_tile_mode == 4 ||
+        (g_bf16_tile_mode == 0 && pp_default && (wants_bnb ? conv3x3_pp_preferred_bnb(P) : conv3x3_pp_preferred(P))))
+      return launch_conv3x3_pp(P, o, s);
+  }
   if (conv3x3_rs_eligible(P)) {
     const int64_t t256 = (int64_t)P.B * (P.H / 16) * (P.W / 16) * (P.N / 64);
     if (g_bf16_tile_mode == 3 || (g_bf16_tile_mode == 0 && t256 >= 512)) return launch_conv3x3_rs(P, o, s);

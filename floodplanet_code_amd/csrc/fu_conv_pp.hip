@@ -17,21 +17,31 @@
 //   * persistent: a workgroup walks its tiles (static round-robin over the XCD-aware tile order) as ONE flat sequence of
 //     (tile, chunk) steps -- the first chunk of the next tile is fetched and staged while the last chunk of this tile is
 //     multiplied, and a group's epilogue (convert, statistics, stores) runs while the other group multiplies.
-//   * every weight fragment a group reads was DMA'd by the OTHER group one phase earlier, and the halo rows a wave needs first
-//     (rows with bit 2 clear) are staged by group 1: the first fragments of an MFMA phase are complete before the barrier
-//     that opens it.
+//   * every weight fragment a group reads was DMA'd by the OTHER group at least one phase earlier, and the halo rows a wave
+//     needs first (rows with bit 2 clear) are converted by group 0, whose conversion of a step ends one phase before group
+//     0's and two phases before group 1's MFMA phase of that step: the first fragments of an MFMA phase are complete
+//     before the barrier that opens it and are requested ahead of that barrier.
 // Accumulation order per output element (chunk, column shift, kernel row) and the statistics' summation order are those of
 // k_conv3x3_bf16_rs<8>: outputs, BatchNorm statistics and fused BatchNorm-backward sums are bit-identical to it (tested).
 // Shapes (conv3x3_pp_eligible): the row-stationary kernel's, with H % 32 == 0.
 #include "fu_conv_bf16.h"
+#include <stdlib.h>
 
 namespace fu {
 
 #if FU_HALF
 #define FU_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define FU_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+#define FU_ASM_UNPK_LO "v_cvt_f32_f16 %0, %1"
+#define FU_ASM_UNPK_HI "v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+#define FU_ASM_PACK "v_cvt_pk_f16_f32 %0, %1, %2"
 #define k_conv3x3_bf16_pp k_conv3x3_f16_pp
 #else
 #define FU_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define FU_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#define FU_ASM_UNPK_LO "v_lshlrev_b32 %0, 16, %1"
+#define FU_ASM_UNPK_HI "v_and_b32 %0, 0xffff0000, %1"
+#define FU_ASM_PACK "v_cvt_pk_bf16_f32 %0, %1, %2"
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,24 +50,49 @@ struct PCfg {
   static constexpr int HWd = TW + 2, HHt = TH + 2, NHP = HHt * HWd;          // 18 x 34 = 612 halo pixels
   static constexpr int ROWB = 64;                                            // bytes per LDS row (32 channels)
   static constexpr int A_BYTES = NHP * ROWB, W_BYTES = 9 * BN * ROWB;        // 39168 + 36864
-  static constexpr int STAGE = A_BYTES + W_BYTES;                            // 76032 per stage
+  static constexpr int STAGE = A_BYTES + W_BYTES;                            // 76032 per stage; LDS image: [A0][A1][W0][W1] (the
+  static constexpr int W_OFF = 2 * A_BYTES;                                  //  A stages 39168 B apart: a ds_write immediate)
   static constexpr int A_ITERS = 5;                                          // staging slots per thread (16-byte units)
-  // group 1 stages the 16 halo rows with bit 2 clear below row 32 + most of rows 32 / 33: 5 full slots (1280 units);
-  // group 0 the 16 rows with bit 2 set (1152 units) + the last 4 pixels of row 33 (16 units): 4 full slots + 144 threads
-  static constexpr int G0_ROW_UNITS = 16 * HWd * 4, G0_UNITS = G0_ROW_UNITS + 16;
+  // group 0 stages the 16 halo rows with bit 2 clear below row 32 + most of rows 32 / 33: 5 full slots (1280 units);
+  // group 1 the 16 rows with bit 2 set (1152 units) + the last 4 pixels of row 33 (16 units): 4 full slots + 144 threads
+  static constexpr int G1_ROW_UNITS = 16 * HWd * 4, G1_UNITS = G1_ROW_UNITS + 16;
   static constexpr int AB_OFF = 2 * STAGE, AB_FLOATS = 1024;                 // BN scale / shift of source 0
   static constexpr int RED_OFF = AB_OFF + AB_FLOATS * 4, RED_FLOATS = 2 * 8 * 32 * 2;   // [tile parity][wave][32 ch][2]
   static constexpr int SMEM_BYTES = RED_OFF + RED_FLOATS * 4;                // 160256 <= 163840
   static constexpr int M_STEPS = 3 * (8 + 2);                                // (column shift, input row) steps per chunk
 };
 
+// ---- issue-slot plan of the MFMA phase (see mfma_phase): gaps = the 144 MFMAs of a chunk in order; per (column shift dx, input
+// row ri) step 2 / 4 / 6 / ... / 6 / 4 / 2 MFMAs (rows 0, 1 and 8, 9 feed fewer output rows)
+constexpr int pp_step_mfmas(int ri) { return ri == 0 || ri == 9 ? 2 : ri == 1 || ri == 8 ? 4 : 6; }
+constexpr int pp_step_first_gap(int ri) { int g = 0; for (int r = 0; r < ri; ++r) g += pp_step_mfmas(r); return g; }
+constexpr int pp_gap_free(int g) {          // free issue slots (of two) behind MFMA g of the phase
+  const int dx = g / 48, gg = g % 48;
+  int ri = 0;
+  while (gg >= pp_step_first_gap(ri) + pp_step_mfmas(ri)) ++ri;
+  const int k = gg - pp_step_first_gap(ri), nm = pp_step_mfmas(ri);
+  const bool has_w = dx < 2 && ri < 6;
+  int used = 0;
+  if (k == 0) used += 1;                               // pixel-fragment read
+  if (has_w && k == (nm > 2 ? 1 : 0)) used += 1;       // weight-fragment read
+  if (k == nm - 1) used += 1;                          // s_waitcnt of the next step's first MFMA
+  return used >= 2 ? 0 : 2 - used;
+}
+constexpr int pp_ops_before(int g) { int n = 0; for (int i = 0; i < g; ++i) n += pp_gap_free(i); return n; }
+
 // BNB: the launch also emits the BatchNorm-backward sums of its destination (BnbFuse; never together with forward
 // statistics or a BatchNorm prologue) -- a separate instantiation, because the y rows of that epilogue would otherwise
 // set the register budget of every launch (223 registers without them, spills with them).
-template <bool BNB>
+// BN: source 0 carries a BatchNorm + ReLU prologue (the conversion pieces exist only in this instantiation; a second,
+// plain source takes a = 1, b = 0 and a NaN floor, so that the instruction stream of a step does not depend on its source --
+// a run-time choice between two MFMA phases made hipcc spill 157 registers at the join).
+// FWD: a forward launch -- bias and the per-tile BatchNorm statistics (sum, sum of squares) of the epilogue exist only here; a
+// dgrad launch has neither, and its epilogue is a third of the vector instructions (the epilogue runs beside the other
+// group's MFMA phase and gets the vector issue port only in the gaps that phase leaves: 5000-7500 cycles in the first build).
+template <bool BNB, bool BN, bool FWD>
 __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   using Cfg = PCfg;
-  constexpr int HWd = Cfg::HWd, ROWB = Cfg::ROWB, KC = Cfg::KC, A_ITERS = Cfg::A_ITERS, STAGE = Cfg::STAGE;
+  constexpr int HWd = Cfg::HWd, ROWB = Cfg::ROWB, KC = Cfg::KC, A_ITERS = Cfg::A_ITERS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sAB = reinterpret_cast<float*>(smem_raw + Cfg::AB_OFF);     // [2][512]
   float* sRed = reinterpret_cast<float*>(smem_raw + Cfg::RED_OFF);
@@ -69,7 +104,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   const int lx = lane & 15, lg = lane >> 4;                          // pixel column / channel row m, and k-group (8 channels)
   const int grid = gridDim.x;
   const int nChunks = P.Cin / KC;
-  const bool has_bn = P.a0 != nullptr;
 
   auto decode = [&](int v, int& pixT, int& n0, int& x0, int& y0, int& bb) __attribute__((always_inline)) {
     const int logical = xcd_remap(v, P.nTiles);
@@ -82,42 +116,46 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     x0 = tx * Cfg::TW; y0 = ty * Cfg::TH; n0 = coT * Cfg::BN;
   };
 
-  // ---- staging slots of this thread: unit ul = tg + 256 it of its group's share of the halo tile (thread constants)
+  // ---- staging slots of this thread: unit ul = tg + 256 it of its group's share of the halo tile (thread constants).
+  //      Group 0 owns the halo rows with bit 2 clear (0-3, 8-11, ..., 32, 33) except the last 4 pixels of row 33: 5 full
+  //      slots; group 1 the rows with bit 2 set + those 4 pixels: 4 full slots + 144 threads -- its other 112 threads repeat
+  //      their slot 3 in slot 4 (same address, same data: no dead slot, so no exec-masked store into which hipcc would sink
+  //      the slot's whole conversion, away from the MFMAs).  The first rows a wave's MFMA phase reads, 8 rg + [0, PD), are
+  //      group 0's: see mfma_prefetch.
   const int aq = tid & 3;
   unsigned lds_a[A_ITERS];
-  unsigned a_live = 0;
   auto slot_yx = [&](int it, int& hy, int& hx) __attribute__((always_inline)) {   // halo row / column of slot it
-    const int ul = tg + it * Cfg::GT;
+    int ul = tg + it * Cfg::GT;
+    if (grp && ul >= Cfg::G1_UNITS) ul -= Cfg::GT;
     const int lp = ul >> 2;
     const int lr = (lp * 3641) >> 16;                                // lp / 18
     hx = lp - lr * HWd;
-    hy = 8 * (lr >> 2) + (lr & 3) + (grp ? 0 : 4);
-    if (!grp && ul >= Cfg::G0_ROW_UNITS) { hy = Cfg::HHt - 1; hx = min(14 + ((ul - Cfg::G0_ROW_UNITS) >> 2), HWd - 1); }
+    hy = 8 * (lr >> 2) + (lr & 3) + (grp ? 4 : 0);
+    if (grp && ul >= Cfg::G1_ROW_UNITS) { hy = Cfg::HHt - 1; hx = min(14 + ((ul - Cfg::G1_ROW_UNITS) >> 2), HWd - 1); }
   };
   static_for<0, A_ITERS>([&](auto I) {
     constexpr int it = decltype(I)::value;
     int hy, hx;
     slot_yx(it, hy, hx);
-    const bool live = grp || tg + it * Cfg::GT < Cfg::G0_UNITS;
-    a_live |= live ? (1u << it) : 0u;
     lds_a[it] = (unsigned)((hy * HWd + hx) * ROWB + ((16 * aq) ^ ((hx & 4) << 3)));
   });
 
-  // ---- cursors over the workgroup's flat sequence of (tile, chunk) steps; both saturate at the last step (the loads / stores
-  //      past the end repeat it into a stage nobody reads any more: no conditional loads in the MFMA phase).
-  //      LOAD cursor: the step whose activation units are requested next -- two steps ahead of their conversion: a staging
-  //      phase converts one register set and refills it at once with the loads of the step after next (with one MFMA
-  //      phase of cover the staging phase measured 2700-4200 cycles, most of it waiting for HBM).  The loads sit at the END
-  //      of the staging phase: vmcnt counts in order, so behind the weight DMA they are not waited for by its vmcnt(0),
-  //      and the MFMA phase carries no vector-memory instruction at all.
-  //      STAGE cursor: the step that is converted / stored / whose weights are DMA'd next.
+  // ---- cursors over the workgroup's flat sequence of (tile, chunk) steps; all saturate at the last step (loads, stores and
+  //      DMA past the end repeat it into a stage nobody reads any more: nothing in the loop is conditional on the step).
+  //      LOAD cursor: the step whose activation units are requested next; three steps ahead of the MFMA cursor: a register
+  //      set is converted during one MFMA phase and refilled in the phase after it with the step after next (with a single
+  //      phase of cover the conversion measured 2700-4200 cycles, most of it waiting for HBM).
+  //      CONVERT cursor: the chunk converted / stored during the current MFMA phase (one step ahead of it).
+  //      DMA cursor: the step whose weights (the OTHER group's half) are DMA'd next: one step ahead for group 0, two for
+  //      group 1 (whose idle phase comes before the MFMA phase of the same step).
   const int R = (P.nTiles - (int)blockIdx.x + grid - 1) / grid;      // tiles of this workgroup (>= 1)
   const int T = R * nChunks;                                         // steps
   int lv = blockIdx.x, lk = 0, lstep = 0;
-  int sv = blockIdx.x, sk = 0, sstep = 0;
+  int dv = blockIdx.x, dk = 0, dstep = 0;
+  int ck = 0, cstep = 0;
   unsigned a_pix[A_ITERS];                                           // clamped pixel index of the slot (< 2^24: eligibility)
-  unsigned a_ok = 0;                                                 // bit it: pixel inside the image (and slot live)
-  size_t w_tile = 0;                                                 // byte offset of the staged tile's first weight row
+  unsigned a_ok = 0;                                                 // bit it: pixel inside the image
+  size_t w_tile = 0;                                                 // byte offset of the DMA cursor's tile's first weight row
   auto load_tile = [&](int v) __attribute__((always_inline)) {
     int pixT, n0, x0, y0, bb;
     decode(v, pixT, n0, x0, y0, bb);
@@ -132,9 +170,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
       a_ok |= ok ? (1u << it) : 0u;
       a_pix[it] = (unsigned)((bb * P.H + cy) * P.W + cx);
     });
-    a_ok &= a_live;
   };
-  auto stage_tile = [&](int v) __attribute__((always_inline)) {
+  auto dma_tile = [&](int v) __attribute__((always_inline)) {
     int pixT, n0, x0, y0, bb;
     decode(v, pixT, n0, x0, y0, bb);
     w_tile = (size_t)n0 * (size_t)P.Cin * 2;
@@ -145,10 +182,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
       if (++lk == nChunks) { lk = 0; lv += grid; load_tile(lv); }
     }
   };
-  auto advance_stage = [&]() __attribute__((always_inline)) {
-    if (sstep + 1 < T) {
-      ++sstep;
-      if (++sk == nChunks) { sk = 0; sv += grid; stage_tile(sv); }
+  auto advance_dma = [&]() __attribute__((always_inline)) {
+    if (dstep + 1 < T) {
+      ++dstep;
+      if (++dk == nChunks) { dk = 0; dv += grid; dma_tile(dv); }
+    }
+  };
+  auto advance_convert = [&]() __attribute__((always_inline)) {
+    if (cstep + 1 < T) {
+      ++cstep;
+      if (++ck == nChunks) ck = 0;
     }
   };
 
@@ -160,9 +203,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   const int dm = lane >> 2, dgk = (lane & 3) ^ ((dm & 4) >> 1);
   const unsigned w_lane = (unsigned)((8 * (dm >> 2) + (dm & 3)) * P.Cin + 8 * dgk) * 2u;
   const size_t w_tap = (size_t)P.N * (size_t)P.Cin * 2;
-  auto dma_weights = [&](int k0, unsigned sb) __attribute__((always_inline)) {
+  auto dma_weights = [&](int st) __attribute__((always_inline)) {   // the DMA cursor's step -> stage st; the cursor moves on
     const int oh = 1 - grp;                                          // the channel half this group stages
-    const char* ub = reinterpret_cast<const char*>(P.wpk) + w_tile + (size_t)k0 * 2 + (size_t)(32 * oh) * (size_t)P.Cin * 2;
+    const char* ub = reinterpret_cast<const char*>(P.wpk) + w_tile + (size_t)(dk * KC) * 2 + (size_t)(32 * oh) * (size_t)P.Cin * 2;
     unsigned wl = w_lane;
     asm volatile("" : "+v"(wl));                                     // (opaque: see fu_conv_rs.hip, hoisted 64-bit lane addresses)
 #pragma unroll
@@ -172,64 +215,113 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
         const int tap = j >> 1, q = j & 1;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(ub + (size_t)tap * w_tap + (size_t)(4 * q) * (size_t)P.Cin * 2 + (size_t)wl),
-            (__attribute__((address_space(3))) void*)(smem_raw + sb + Cfg::A_BYTES + tap * (Cfg::BN * ROWB) + (2 * oh + q) * 1024),
+            (__attribute__((address_space(3))) void*)(smem_raw + Cfg::W_OFF + st * Cfg::W_BYTES + tap * (Cfg::BN * ROWB) + (2 * oh + q) * 1024),
             16, 0, 0);
       }
     }
+    advance_dma();
   };
 
-  // ---- activation loads (registers) and the convert + store into an LDS stage
-  uint4 ra[2][A_ITERS];                                              // two steps in flight
+  // ---- activation loads (registers): two sets = two steps in flight
+  uint4 ra[2][A_ITERS];
   unsigned okset[2] = {0u, 0u};                                      // the zero-padding mask travels with its set
-  const char* abL = nullptr;
-  unsigned cs2 = 0;                                                  // bytes per pixel of the current source (uniform)
-  auto load_begin = [&](auto Set) __attribute__((always_inline)) {
+  auto load_all = [&](auto Set) __attribute__((always_inline)) {    // the load cursor's step -> set; the cursor moves on
     constexpr int set = decltype(Set)::value;
     okset[set] = a_ok;
     const int k0 = lk * KC;
     const bool s1 = P.src1 != nullptr && k0 >= P.C0;                 // uniform
-    abL = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
-             : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
-    cs2 = (unsigned)(s1 ? P.C1 : P.C0) * 2u;
+    const char* abL = s1 ? reinterpret_cast<const char*>(P.src1) + (size_t)(k0 - P.C0) * 2
+                         : reinterpret_cast<const char*>(P.src0) + (size_t)k0 * 2;
+    const unsigned cs2 = (unsigned)(s1 ? P.C1 : P.C0) * 2u;          // bytes per pixel of the source
+    // uniform base + 32-bit lane offset = pixel * (channels * 2) + 16 aq: one v_mad_u32_u24 per load
+    static_for<0, A_ITERS>([&](auto Sc) {
+      constexpr int sl = decltype(Sc)::value;
+      ra[set][sl] = *reinterpret_cast<const uint4*>(abL + ((a_pix[sl] & 0xffffffu) * (cs2 & 0xffffffu) + 16u * aq));
+    });
+    advance_load();
   };
-  auto load_slot = [&](auto Set, auto Sc) __attribute__((always_inline)) {
-    constexpr int set = decltype(Set)::value, sl = decltype(Sc)::value;
-    ra[set][sl] = *reinterpret_cast<const uint4*>(abL + ((a_pix[sl] & 0xffffffu) * (cs2 & 0xffffffu) + 16u * aq));
-  };
-  auto store_chunk = [&](unsigned sb, auto Set, auto Bc) __attribute__((always_inline)) {
-    constexpr bool BNR = decltype(Bc)::value;
-    constexpr int set = decltype(Set)::value;
-    unsigned okm = okset[set];
-    asm volatile("" : "+v"(okm));
-    const int cc = (BNR ? sk * KC : 0) + 8 * aq;                     // < 512: inside sAB
-    f32x2 ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3;
-    if constexpr (BNR) {
+  // ---- convert + store of a set into an LDS stage, in PIECES that the MFMA phase spreads between its MFMAs (one wave
+  //      issues an MFMA every 16 cycles and the matrix pipe holds the vector issue port for 8 of them: its own VALU work in
+  //      the other 8 is nearly free, while the SAME work issued by the partner wave of the SIMD measured 8-11 cycles per
+  //      instruction -- 1900-2100 cycles for the 175 instructions of a BatchNorm + ReLU conversion, the phase's critical path).
+  //      Piece (unit it, pair j < 4): relu(a * x + b) of one channel pair; piece (it, 4): zero-padding mask + ds_write_b128.
+  f32x2 cva[4], cvb[4];                                              // BatchNorm scale / shift of this lane's 8 channels
+  int cfloor = 0;                                                    // ReLU floor on the float's bits: 0, or INT_MIN (identity)
+  auto convert_coeffs = [&]() __attribute__((always_inline)) {
+    if (ck * KC < P.C0) {                                            // uniform: a chunk of the BatchNorm-activated source
+      const int cc = ck * KC + 8 * aq;                               // < 512: inside sAB
       const float4 a0 = *reinterpret_cast<const float4*>(sAB + cc);
       const float4 a1 = *reinterpret_cast<const float4*>(sAB + cc + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(sAB + 512 + cc);
       const float4 b1 = *reinterpret_cast<const float4*>(sAB + 512 + cc + 4);
-      ca0 = f32x2{a0.x, a0.y}; ca1 = f32x2{a0.z, a0.w}; ca2 = f32x2{a1.x, a1.y}; ca3 = f32x2{a1.z, a1.w};
-      cb0 = f32x2{b0.x, b0.y}; cb1 = f32x2{b0.z, b0.w}; cb2 = f32x2{b1.x, b1.y}; cb3 = f32x2{b1.z, b1.w};
+      cva[0] = f32x2{a0.x, a0.y}; cva[1] = f32x2{a0.z, a0.w}; cva[2] = f32x2{a1.x, a1.y}; cva[3] = f32x2{a1.z, a1.w};
+      cvb[0] = f32x2{b0.x, b0.y}; cvb[1] = f32x2{b0.z, b0.w}; cvb[2] = f32x2{b1.x, b1.y}; cvb[3] = f32x2{b1.z, b1.w};
+      cfloor = 0;
+    } else {                                                         // a chunk of the plain second source: identity
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cva[j] = f32x2{1.f, 1.f}; cvb[j] = f32x2{0.f, 0.f}; }
+      cfloor = (int)0x80000000u;
     }
-    static_for<0, A_ITERS>([&](auto I) {
-      constexpr int it = decltype(I)::value;
-      if (it < A_ITERS - 1 || ((a_live >> it) & 1u)) {
-        unsigned x = ra[set][it].x, y = ra[set][it].y, z = ra[set][it].z, w = ra[set][it].w;
-        if constexpr (BNR) {
-          x = bn_relu_pair(x, ca0, cb0); y = bn_relu_pair(y, ca1, cb1);
-          z = bn_relu_pair(z, ca2, cb2); w = bn_relu_pair(w, ca3, cb3);
-        }
-        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)okm, it, 1);     // bit it -> 0 / 0xffffffff (zero padding)
-        x &= m; y &= m; z &= m; w &= m;
-        *reinterpret_cast<uint4*>(smem_raw + sb + lds_a[it]) = make_uint4(x, y, z, w);
-      }
-    });
   };
-  // one staging phase: this group's half of the step under the cursor -> stage `sb`, then the cursor moves on
-  auto load_all = [&](auto Set) __attribute__((always_inline)) {
-    load_begin(Set);
-    static_for<0, A_ITERS>([&](auto Sc) { load_slot(Set, Sc); });
-    advance_load();
+  // The conversion as a sequence of SINGLE vector instructions, each pinned (an empty asm on its result: pure arithmetic has no
+  // chain to a sched_barrier -- unpinned, the DAG linearisation gathers it at its use) so that the MFMA phase can put it into a
+  // chosen issue slot.  Per unit: [BN: per channel pair: unpack lo | unpack hi | fma lo | max lo | fma hi | max hi | pack]
+  // then [mask bit | and x | and y | and z | and w | ds_write_b128].
+  float cvl[2] = {0.f, 0.f}, cvh[2] = {0.f, 0.f};                    // two channel pairs in flight
+  unsigned cv_m = 0u;
+  constexpr int OPU = BN ? 34 : 6, NOPS = OPU * A_ITERS;             // operations per unit / per step
+  // Every vector instruction of the conversion is an inline-asm statement: behind an inline-asm MFMA hipcc pads each of ITS OWN
+  // vector instructions with an s_nop (one issue slot each).  It also pads an asm statement that reads a register an asm
+  // statement wrote less than ~3 instructions earlier (it has to take it for a transcendental), so two channel pairs A / B run
+  // interleaved and every result is used 4 operations after it is made.  Per unit (BN): mask bit | 2 x { unpack loA hiA loB hiB |
+  // fma loA hiA loB hiB | max loA hiA loB hiB | pack A B } | and x y z w | ds_write_b128.  ReLU = signed-integer max of the
+  // float's bits against 0 (negative floats are negative integers; -0 -> +0 as v_max_f32 gives) or against INT_MIN (identity:
+  // a chunk of the plain source).
+  auto convert_op = [&](auto Stg, auto Set, auto Kc) __attribute__((always_inline)) {
+    constexpr int stg = decltype(Stg)::value, set = decltype(Set)::value, k = decltype(Kc)::value;
+    constexpr int it = k / OPU, r = k % OPU;
+    constexpr int so = BN ? (r == 0 ? 0 : r >= 29 ? r - 28 : -1) : r;   // >= 0: mask / store part
+    if constexpr (so < 0) {
+      constexpr int d = (r - 1) / 14, op = (r - 1) % 14;             // double pair d (words 2 d, 2 d + 1), operation
+      constexpr int ph = op / 4, ab = op < 12 ? (op % 4) / 2 : op - 12, hl = op % 2;   // phase, pair A / B, lo / hi
+      constexpr int j = 2 * d + ab;
+      // (component by component: a select between lvalues takes addresses and demotes the register array to scratch)
+      if constexpr (op < 4) {
+        unsigned w = 0;
+        if constexpr (j == 0) w = ra[set][it].x;
+        if constexpr (j == 1) w = ra[set][it].y;
+        if constexpr (j == 2) w = ra[set][it].z;
+        if constexpr (j == 3) w = ra[set][it].w;
+        if constexpr (hl == 0) asm volatile(FU_ASM_UNPK_LO : "=v"(cvl[ab]) : "v"(w));
+        else asm volatile(FU_ASM_UNPK_HI : "=v"(cvh[ab]) : "v"(w));
+      } else if constexpr (ph == 1) {
+        if constexpr (hl == 0) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(cvl[ab]) : "v"(cva[j].x), "v"(cvb[j].x));
+        else asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(cvh[ab]) : "v"(cva[j].y), "v"(cvb[j].y));
+      } else if constexpr (ph == 2) {
+        if constexpr (hl == 0) asm volatile("v_max_i32 %0, %1, %0" : "+v"(cvl[ab]) : "s"(cfloor));
+        else asm volatile("v_max_i32 %0, %1, %0" : "+v"(cvh[ab]) : "s"(cfloor));
+      } else {
+        unsigned w;
+        asm volatile(FU_ASM_PACK : "=v"(w) : "v"(cvl[ab]), "v"(cvh[ab]));
+        if constexpr (j == 0) ra[set][it].x = w;
+        if constexpr (j == 1) ra[set][it].y = w;
+        if constexpr (j == 2) ra[set][it].z = w;
+        if constexpr (j == 3) ra[set][it].w = w;
+      }
+    } else if constexpr (so == 0) {
+      asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(cv_m) : "v"(okset[set]), "n"(it));   // bit it -> 0 / 0xffffffff (zero padding)
+    } else if constexpr (so == 1) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(ra[set][it].x) : "v"(cv_m));
+    } else if constexpr (so == 2) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(ra[set][it].y) : "v"(cv_m));
+    } else if constexpr (so == 3) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(ra[set][it].z) : "v"(cv_m));
+    } else if constexpr (so == 4) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(ra[set][it].w) : "v"(cv_m));
+    } else {
+      *reinterpret_cast<uint4*>(smem_raw + stg * Cfg::A_BYTES + lds_a[it]) = ra[set][it];   // (stage offset: an immediate)
+    }
+  };
+  auto convert_all = [&](auto Stg, auto Set) __attribute__((always_inline)) {   // (prologue: step 0, no MFMAs beside it)
+    if constexpr (BN) convert_coeffs();
+    static_for<0, NOPS>([&](auto Kc) { convert_op(Stg, Set, Kc); });
+    advance_convert();
   };
 #ifdef FU_CONV_STAMPS     // diagnostic builds only (tools/stamp_pp.py): s_memtime sums per phase and wave
   unsigned long long tM = 0, tB1 = 0, tS = 0, tE = 0, tB2 = 0, tSd = 0, tSw = 0, tSc = 0, tSv = 0, tSl = 0;
@@ -237,27 +329,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #else
 #define FU_STAMP(v)
 #endif
-  auto stage_phase = [&](unsigned sb, auto Set) __attribute__((always_inline)) {
-    const int k0 = sk * KC;
-    FU_STAMP(q0);
-    dma_weights(k0, sb);
-    FU_STAMP(q1);
-#ifdef FU_CONV_STAMPS
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");               // the set's five loads (older than the other set's and the DMA)
-#endif
-    FU_STAMP(q2);
-    if (has_bn && k0 < P.C0) store_chunk(sb, Set, std::true_type{});
-    else store_chunk(sb, Set, std::false_type{});
-    FU_STAMP(q3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's LDS-DMA pieces have landed (the other set's
-    advance_stage();                                                 //  loads too: they are a whole step old)
-    FU_STAMP(q4);
-    load_all(Set);                                                   // refill the set: the step after next
-#ifdef FU_CONV_STAMPS
-    const unsigned long long q5 = __builtin_amdgcn_s_memtime();
-    tSd += q1 - q0; tSw += q2 - q1; tSc += q3 - q2; tSv += q4 - q3; tSl += q5 - q4;
-#endif
-  };
 
   // ---- MFMA phase
   f32x4 acc[8][2];
@@ -269,11 +340,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   unsigned wfb[2], pfb[2][3];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
-    wfb[par] = (unsigned)(par * STAGE + Cfg::A_BYTES + (2 * grp) * 1024 + lx * ROWB + ((16 * lg) ^ ((lx & 4) << 3)));
+    wfb[par] = (unsigned)(Cfg::W_OFF + par * Cfg::W_BYTES + (2 * grp) * 1024 + lx * ROWB + ((16 * lg) ^ ((lx & 4) << 3)));
     asm volatile("" : "+v"(wfb[par]));
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      pfb[par][dx] = (unsigned)(par * STAGE + (rg * 8 * HWd + lx + dx) * ROWB + ((16 * lg) ^ (((lx + dx) & 4) << 3)));
+      pfb[par][dx] = (unsigned)(par * Cfg::A_BYTES + (rg * 8 * HWd + lx + dx) * ROWB + ((16 * lg) ^ (((lx + dx) & 4) << 3)));
       asm volatile("" : "+v"(pfb[par][dx]));
     }
   }
@@ -281,7 +352,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #ifndef FU_PP_PD
 #define FU_PP_PD 3
 #endif
-  constexpr int PD = FU_PP_PD, NR = PD + 1;
+  constexpr int PD = FU_PP_PD, NR = PD + 2;   // (PD + 2 slots: the slot a read overwrites was last multiplied a whole step ago --
+                                              //  with PD + 1 hipcc pads every such read with s_nop wait states behind the MFMA)
   static_assert(PD <= 4, "the rows requested ahead of the barrier (halo rows 8 rg + [0, PD)) must be group 1's: bit 2 clear");
   frag8_t pf[NR];                          // ring of input-row fragments, PD steps ahead of the MFMAs
   auto ld_w = [&](auto Par, auto Bk, auto Dy, auto Q) __attribute__((always_inline)) {
@@ -300,61 +372,104 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     });
     static_for<0, PD>([&](auto Tc) { ld_p(Par, Tc); });
   };
+  // The MFMA phase of a step (stage Par) + this wave's conversion of the NEXT step's units (set 1 - Par -> stage 1 - Par).
+  // Issue rules measured with tools/probes/mfma16_issue_probe.hip: a wave issues one instruction per 4-cycle turn of its SIMD;
+  // v_mfma_f32_16x16x32 takes two turns and the matrix pipe 16 cycles, so exactly TWO other instructions of any kind (VALU,
+  // ds_read, s_waitcnt, s_nop, SALU) fit behind an MFMA for free -- the third costs 4 cycles, the fourth 5 more -- and a partner
+  // wave's VALU takes what the older wave leaves.  Hence: MFMAs in place (inline asm: hipcc renames the accumulators, dst !=
+  // src C, and then pads the reuse of the freed registers with s_nop), every (MFMA + its slot instructions) fenced by a
+  // sched_barrier, and the slots given out by a fixed plan (pp_gap_free): gap 0 of a (column shift, input row) step holds the
+  // pixel-fragment read PD steps ahead, gap 1 the next column shift's weight fragment (steps 0-5), the last gap leaves a slot to
+  // the s_waitcnt in front of the next step's first MFMA; everything else takes the conversion, one instruction per slot.
   auto mfma_phase = [&](auto Par) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value;
+    // The fragments requested ahead of the barrier are "used" here, before any new read is issued: hipcc's waitcnt pass loses
+    // count of them across the barrier / loop edge and would otherwise wait with lgkmcnt(0) at their first MFMA.
+    auto touch = [](const frag8_t& f) __attribute__((always_inline)) { asm volatile("" :: "v"(f)); };
+    static_for<0, 3>([&](auto Dy) { touch(wf[0][decltype(Dy)::value][0]); touch(wf[0][decltype(Dy)::value][1]); });
+    static_for<0, PD>([&](auto Tc) { touch(pf[decltype(Tc)::value]); });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BN) convert_coeffs();
     static_for<0, Cfg::M_STEPS>([&](auto Tc) {
       constexpr int t = decltype(Tc)::value, dx = t / 10, ri = t % 10;
-      if constexpr (t + PD < Cfg::M_STEPS) ld_p(Par, std::integral_constant<int, t + PD>{});
-      if constexpr (dx < 2 && ri < 6)      // the next column shift's six weight fragments, one per step
-        ld_w(Par, std::integral_constant<int, dx + 1>{}, std::integral_constant<int, ri / 2>{}, std::integral_constant<int, ri % 2>{});
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, 3>([&](auto Yc) {
-        constexpr int dy = decltype(Yc)::value, ro = ri - dy;
-        if constexpr (ro >= 0 && ro < 8) {
-          acc[ro][0] = FU_MFMA16(wf[dx & 1][dy][0], pf[t % NR], acc[ro][0]);
-          acc[ro][1] = FU_MFMA16(wf[dx & 1][dy][1], pf[t % NR], acc[ro][1]);
-        }
+      constexpr int nm = pp_step_mfmas(ri);
+      static_for<0, nm>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr int dy = (ri < 8 ? 0 : ri - 7) + k / 2, q = k % 2, ro = ri - dy;
+        static_assert(ro >= 0 && ro < 8, "kernel row of the k-th MFMA of a step");
+        asm volatile(FU_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[ro][q]) : "v"(wf[dx & 1][dy][q]), "v"(pf[t % NR]));
+#ifndef FU_PP_EXP_NOREAD     // (timing experiments of diagnostic builds: wrong results)
+        if constexpr (k == 0 && t + PD < Cfg::M_STEPS) ld_p(Par, std::integral_constant<int, (t + PD < Cfg::M_STEPS ? t + PD : 0)>{});
+        if constexpr (k == (nm > 2 ? 1 : 0) && dx < 2 && ri < 6)     // the next column shift's six weight fragments, one per step
+          ld_w(Par, std::integral_constant<int, dx + 1>{}, std::integral_constant<int, (ri < 6 ? ri / 2 : 0)>{}, std::integral_constant<int, ri % 2>{});
+#endif
+#ifndef FU_PP_EXP_NOCONV
+        constexpr int g = 48 * dx + pp_step_first_gap(ri) + k;       // gap index in the phase
+        constexpr int o0 = pp_ops_before(g), o1 = o0 + pp_gap_free(g);
+        static_for<o0, (o1 < NOPS ? o1 : NOPS)>([&](auto Oc) {
+          convert_op(std::integral_constant<int, 1 - par>{}, std::integral_constant<int, 1 - par>{}, Oc);
+        });
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       });
     });
+    static_assert(pp_ops_before(144) >= NOPS, "not enough issue slots for the conversion");
+    advance_convert();
   };
 
-  // ---- epilogue of the tile under the MFMA cursor: lane (pixel lx, group lg) holds channels n0 + 32 grp + 8 lg + [0, 8)
   int mv = blockIdx.x, mk = 0, tpar = 0, mstep = 0;
+  // ---- epilogue of the tile under the MFMA cursor: lane (pixel lx, group lg) holds channels n0 + 32 grp + 8 lg + [0, 8)
   int pend_pixT = 0, pend_n0 = 0, pend_par = 0;
   bool pend = false;
-  auto row_sum = [](float v) __attribute__((always_inline)) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
-    return v;
+  // Sum over the 16 lanes (pixels) of a row group: row_shr 1, 2, 4, 8, lane 15 of every row ends with the total.  ONE
+  // v_add_f32_dpp per step and value (hipcc emits v_mov_b32_dpp + v_add_f32 for the update_dpp form: twice the instructions),
+  // the N values of a lane interleaved so that a value's next step is N instructions away (a DPP read needs two wait states
+  // behind the VALU write of its operand).  v + shr(v) is the same sum as the two-instruction form: bit-identical results.
+  auto row_sums = [](auto& v) __attribute__((always_inline)) {
+    constexpr int N = sizeof(v) / sizeof(float);
+    static_assert(N >= 4, "interleave too short for the DPP wait states");
+    asm volatile("s_nop 1");        // (the last of the values may have been written by the instruction in front: hipcc does not
+                                    //  know these are DPP reads and pads nothing)
+#define FU_RS_STEP(CTRL) _Pragma("unroll") for (int c = 0; c < N; ++c) \
+      asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v[c]));
+    FU_RS_STEP("row_shr:1") FU_RS_STEP("row_shr:2") FU_RS_STEP("row_shr:4") FU_RS_STEP("row_shr:8")
+#undef FU_RS_STEP
+  };
+  // BnbFuse: the y rows of this lane's pixels, requested at the start of the epilogue: they land while the tile is converted
+  // and stored.  (Measured and dropped: requested at the start of the epilogue's phase, the weight-DMA wait behind them stands
+  // still for an HBM latency, 125 -> 154 us on 64 -> 64 at 256 x 256; requested a step ahead under a uniform branch, hipcc's
+  // waitcnt pass merges the two paths into s_waitcnt vmcnt(0) in front of the next MFMA phase's first ds_write, 149 us.)
+  uint4 yr[8];
+  auto bnb_request = [&]() __attribute__((always_inline)) {
+    int pixT, n0, x0, y0, bb;
+    decode(mv, pixT, n0, x0, y0, bb);
+    const char* ybase = reinterpret_cast<const char*>(P.bnb_y) +
+        ((size_t)((bb * P.H + y0 + rg * 8) * P.W + x0 + lx) * (size_t)P.N + (size_t)(n0 + 32 * grp + 8 * lg)) * 2;
+#pragma unroll
+    for (int ro = 0; ro < 8; ++ro) yr[ro] = *reinterpret_cast<const uint4*>(ybase + (size_t)ro * (size_t)(P.W * P.N) * 2);
   };
   auto epilogue = [&]() __attribute__((always_inline)) {
+    if constexpr (BNB) bnb_request();
     int pixT, n0, x0, y0, bb;
     decode(mv, pixT, n0, x0, y0, bb);
     const int nl = n0 + 32 * grp + 8 * lg;
     float* red = sRed + tpar * 512 + (grp * 4 + rg) * 64;            // [32 channels][2]
-    uint4 yr[8];                                                     // BnbFuse: the y rows of this lane's pixels; requested first,
-    if constexpr (BNB) {                                             // they land while the tile is converted and stored
-      const char* ybase = reinterpret_cast<const char*>(P.bnb_y) +
-          ((size_t)((bb * P.H + y0 + rg * 8) * P.W + x0 + lx) * (size_t)P.N + (size_t)nl) * 2;
-#pragma unroll
-      for (int ro = 0; ro < 8; ++ro) yr[ro] = *reinterpret_cast<const uint4*>(ybase + (size_t)ro * (size_t)(P.W * P.N) * 2);
-    }
     const bool to0 = n0 < P.D0;                                      // uniform: D0 % 64 == 0 with two destinations
     char* dbase = reinterpret_cast<char*>(to0 ? P.dst0 + nl : P.dst1 + (nl - P.D0));
     const int dstride = to0 ? P.D0 : P.D1;
     float biasv[8];
-    if (P.bias != nullptr) {
-      const float4 b0 = *reinterpret_cast<const float4*>(P.bias + nl), b1 = *reinterpret_cast<const float4*>(P.bias + nl + 4);
-      biasv[0] = b0.x; biasv[1] = b0.y; biasv[2] = b0.z; biasv[3] = b0.w;
-      biasv[4] = b1.x; biasv[5] = b1.y; biasv[6] = b1.z; biasv[7] = b1.w;
-    } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) biasv[c] = 0.f;
+    for (int c = 0; c < 8; ++c) biasv[c] = 0.f;
+    if constexpr (FWD) {
+      if (P.bias != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(P.bias + nl), b1 = *reinterpret_cast<const float4*>(P.bias + nl + 4);
+        biasv[0] = b0.x; biasv[1] = b0.y; biasv[2] = b0.z; biasv[3] = b0.w;
+        biasv[4] = b1.x; biasv[5] = b1.y; biasv[6] = b1.z; biasv[7] = b1.w;
+      }
     }
-    float ssum[8], ssq[8];
+    float st[16];                                                    // [0, 8): sums, [8, 16): sums of squares
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+    for (int c = 0; c < 16; ++c) st[c] = 0.f;
 #pragma unroll
     for (int ro = 0; ro < 8; ++ro) {
       const int oy = y0 + rg * 8 + ro, ox = x0 + lx;
@@ -362,27 +477,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const float v0 = acc[ro][q][0], v1 = acc[ro][q][1], v2 = acc[ro][q][2], v3 = acc[ro][q][3];
-        if constexpr (!BNB) {
-          ssum[4 * q + 0] += v0; ssum[4 * q + 1] += v1; ssum[4 * q + 2] += v2; ssum[4 * q + 3] += v3;
-          ssq[4 * q + 0] = fmaf(v0, v0, ssq[4 * q + 0]); ssq[4 * q + 1] = fmaf(v1, v1, ssq[4 * q + 1]);
-          ssq[4 * q + 2] = fmaf(v2, v2, ssq[4 * q + 2]); ssq[4 * q + 3] = fmaf(v3, v3, ssq[4 * q + 3]);
+        if constexpr (FWD) {
+          st[4 * q + 0] += v0; st[4 * q + 1] += v1; st[4 * q + 2] += v2; st[4 * q + 3] += v3;
+          st[8 + 4 * q + 0] = fmaf(v0, v0, st[8 + 4 * q + 0]); st[8 + 4 * q + 1] = fmaf(v1, v1, st[8 + 4 * q + 1]);
+          st[8 + 4 * q + 2] = fmaf(v2, v2, st[8 + 4 * q + 2]); st[8 + 4 * q + 3] = fmaf(v3, v3, st[8 + 4 * q + 3]);
+          o[2 * q + 0] = pack_e2(f32x2{v0 + biasv[4 * q + 0], v1 + biasv[4 * q + 1]});
+          o[2 * q + 1] = pack_e2(f32x2{v2 + biasv[4 * q + 2], v3 + biasv[4 * q + 3]});
+        } else {
+          o[2 * q + 0] = pack_e2(f32x2{v0, v1});
+          o[2 * q + 1] = pack_e2(f32x2{v2, v3});
         }
-        o[2 * q + 0] = pack_e2(f32x2{v0 + biasv[4 * q + 0], v1 + biasv[4 * q + 1]});
-        o[2 * q + 1] = pack_e2(f32x2{v2 + biasv[4 * q + 2], v3 + biasv[4 * q + 3]});
         if constexpr (!BNB) acc[ro][q] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       char* dp = dbase + (size_t)((bb * P.H + oy) * P.W + ox) * (size_t)dstride * 2;
       *reinterpret_cast<uint4*>(dp) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    if constexpr (!BNB) {
+    if constexpr (FWD) {
       if (P.stats) {
+        row_sums(st);
+        if (lx == 15) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float r1 = row_sum(ssum[c]), r2 = row_sum(ssq[c]);
-          if (lx == 15) { red[(8 * lg + c) * 2 + 0] = r1; red[(8 * lg + c) * 2 + 1] = r2; }
+          for (int c = 0; c < 8; ++c) { red[(8 * lg + c) * 2 + 0] = st[c]; red[(8 * lg + c) * 2 + 1] = st[8 + c]; }
         }
       }
-    } else {
+    }
+    if constexpr (BNB) {
       // BatchNorm-backward sums of the destination (BnbFuse, fu_common.h): g = the accumulators (fp32, before their
       // rounding to the element type), y = the BatchNorm's raw input at the same pixels and channels; per channel
       // sum g*m and sum g*m*y over the 8 rows, the 16 pixels of a row (DPP), then the 4 row groups (LDS, by the combine).
@@ -392,7 +511,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
         const float4 a4 = *reinterpret_cast<const float4*>(P.bnb_a + nl + 4 * q);
         const float4 b4 = *reinterpret_cast<const float4*>(P.bnb_b + nl + 4 * q);
         const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+        float tt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // [0, 4): sum g*m, [4, 8): sum g*m*y
 #pragma unroll
         for (int ro = 0; ro < 8; ++ro) {
           const unsigned w01 = q ? yr[ro].z : yr[ro].x, w23 = q ? yr[ro].w : yr[ro].y;
@@ -400,15 +519,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float gm = fmaf(av[k], yv[k], bv[k]) > 0.f ? acc[ro][q][k] : 0.f;
-            t1[k] += gm;
-            t2[k] = fmaf(gm, yv[k], t2[k]);
+            tt[k] += gm;
+            tt[4 + k] = fmaf(gm, yv[k], tt[4 + k]);
           }
           acc[ro][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        row_sums(tt);
+        if (lx == 15) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float r1 = row_sum(t1[k]), r2 = row_sum(t2[k]);
-          if (lx == 15) { red[(8 * lg + 4 * q + k) * 2 + 0] = r1; red[(8 * lg + 4 * q + k) * 2 + 1] = r2; }
+          for (int k = 0; k < 4; ++k) { red[(8 * lg + 4 * q + k) * 2 + 0] = tt[k]; red[(8 * lg + 4 * q + k) * 2 + 1] = tt[4 + k]; }
         }
       });
     }
@@ -429,7 +548,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
       float* o = P.bnb_part + ((int64_t)pend_pixT * P.N + pend_n0 + c) * 2;
       o[0] = s;
       o[1] = fmaf(iv, t, nm * s);                                    // invstd * s2 - mean * invstd * s1
-    } else if (P.stats) {
+    } else if (FWD && P.stats) {
       float* o = P.stats + ((int64_t)pend_pixT * P.N + pend_n0 + c) * 2;
       o[0] = s;
       o[1] = t;
@@ -439,38 +558,50 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 
 #ifdef FU_CONV_STAMPS
   const unsigned long long tStart = __builtin_amdgcn_s_memtime();
+  unsigned long long tPro = 0;
   const unsigned long long rStart = __builtin_amdgcn_s_memrealtime();
   unsigned long long tLoop = 0;
 #endif
 
-  // ---- prologue: coefficient tables, step 0 (both groups), step 1 (group 1, while group 0 multiplies step 0)
-  if (has_bn) {
+  // s_waitcnt vmcnt(5) through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14):
+  // hipcc's waitcnt pass sees it and knows the LDS-DMA pieces have landed -- behind an asm wait it still holds them pending
+  // and puts s_waitcnt vmcnt(0) in front of the first ds_write of the next MFMA phase, i.e. waits for the loads that were
+  // issued to stay in flight for two phases.
+  auto vm_wait5 = []() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(5 | (7 << 4) | (15 << 8)); };
+  // Workgroup barrier of the loop: LDS traffic of this wave done (lgkmcnt), then s_barrier.  __syncthreads() also waits with
+  // vmcnt(0) -- for the activation loads that were issued to stay in flight across two phases (and for the epilogue's stores).
+  // The LDS-DMA pieces, which do count in vmcnt, are waited for explicitly where they are issued.
+  auto wg_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // ---- prologue: coefficient tables, step 0 (both groups convert their halves and DMA the other's weights), the loads of
+  //      steps 1 and 2; group 1 then DMAs group 0's weights of step 1 while group 0 runs its first MFMA phase
+  if constexpr (BN) {
     for (int c = tid; c < P.C0; c += Cfg::NT) { sAB[c] = P.a0[c]; sAB[512 + c] = P.b0[c]; }
   }
   load_tile(lv);
-  stage_tile(sv);
-  // The loop's body<par> converts and refills set 1 - par.  Group 0 enters it after one staging phase (step 0 from set 0),
-  // group 1 after two (step 0 from set 1, step 1 from set 0): steps 0 / 1 go to sets grp / 1 - grp.
-  if (grp) { load_all(std::integral_constant<int, 1>{}); load_all(std::integral_constant<int, 0>{}); }
-  else { load_all(std::integral_constant<int, 0>{}); load_all(std::integral_constant<int, 1>{}); }
-  __syncthreads();                                                   // sAB
+  dma_tile(dv);
+  load_all(std::integral_constant<int, 0>{});                        // step 0 -> set 0
+  dma_weights(0);                                                    // step 0's weights (LDS is free at kernel start)
+  load_all(std::integral_constant<int, 1>{});                        // step 1 -> set 1 (behind the DMA: stays in flight below)
+  vm_wait5();                                                        // step 0's loads, the DMA pieces (and the coefficient tables)
+  wg_barrier();                                                      // sAB
+  convert_all(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // step 0 (set 0) -> stage 0
+  load_all(std::integral_constant<int, 0>{});                        // step 2 -> set 0
+  wg_barrier();                                                      // step 0 complete
   if (grp) {
-    stage_phase(0u, std::integral_constant<int, 1>{});
-    __syncthreads();
-    stage_phase((unsigned)STAGE, std::integral_constant<int, 0>{});
-    mfma_prefetch(std::integral_constant<int, 0>{});                 // group 1: step 0 is complete since the last barrier
-    __syncthreads();
+    dma_weights(1);                                                  // group 0's weights of step 1
+    mfma_prefetch(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));           // vmcnt(0) (once: the loads of steps 1, 2 are older than the DMA)
+    wg_barrier();
   } else {
-    stage_phase(0u, std::integral_constant<int, 0>{});
-    __syncthreads();
+    mfma_prefetch(std::integral_constant<int, 0>{});
   }
-  if (!grp) mfma_prefetch(std::integral_constant<int, 0>{});         // group 0: behind the barrier (step 0 was being staged)
 
+  // One step of a group: { MFMA phase + conversion of the next step ; barrier ; weight DMA, refill of the converted set,
+  // [sums of the previous tile], [epilogue], first fragments of the next MFMA phase ; barrier }.  Group 1 runs one phase
+  // behind group 0, so on every SIMD one wave multiplies while the other moves data.
   auto body = [&](auto Par) __attribute__((always_inline)) {
     constexpr int par = decltype(Par)::value;
-#ifdef FU_CONV_STAMPS
-    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-#endif
+    FU_STAMP(s0);
 #ifdef FU_PP_MPRIO
     __builtin_amdgcn_s_setprio(FU_PP_MPRIO);
 #endif
@@ -478,35 +609,35 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #ifdef FU_PP_MPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-#ifdef FU_CONV_STAMPS
-    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();
-#ifdef FU_CONV_STAMPS
-    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
-#endif
+    FU_STAMP(s1);
+    wg_barrier();
+    FU_STAMP(s2);
     const bool tile_end = mk + 1 == nChunks && mstep < T;            // uniform (an odd step count ends with a dummy step)
     ++mstep;
-    // group 0 stages step s+1 into the other stage; group 1 stages step s+2 into the stage it has just multiplied (group 0
-    // left it one phase ago)
-    stage_phase((unsigned)((grp ? par : 1 - par) * STAGE), std::integral_constant<int, 1 - par>{});
-#ifdef FU_CONV_STAMPS
-    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
-#endif
+    // group 0: the weights of step s+1 (stage 1 - par: group 1 left it one phase ago); group 1: of step s+2 (stage par: group
+    // 0 multiplied it one phase ago, and group 1's own half of that stage is not touched)
+    dma_weights(grp ? par : 1 - par);
+    FU_STAMP(s2a);
+    load_all(std::integral_constant<int, 1 - par>{});                // refill the set this phase's conversion has emptied
+    FU_STAMP(s2b);
+    vm_wait5();                                                      // the DMA pieces have landed (the five loads stay in flight)
+    FU_STAMP(s3);
     if (wave == 0 && pend) combine();
+    FU_STAMP(s3a);
     if (tile_end) { epilogue(); mk = 0; } else { ++mk; }
+    FU_STAMP(s3b);
     mfma_prefetch(std::integral_constant<int, 1 - par>{});           // first fragments of the next MFMA phase (complete: header)
-#ifdef FU_CONV_STAMPS
-    const unsigned long long s4 = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();
+    FU_STAMP(s4);
+    wg_barrier();
 #ifdef FU_CONV_STAMPS
     const unsigned long long s5 = __builtin_amdgcn_s_memtime();
     tM += s1 - s0; tB1 += s2 - s1; tS += s3 - s2; tE += s4 - s3; tB2 += s5 - s4;
+    tSd += s2a - s2; tSl += s2b - s2a; tSv += s3 - s2b; tSw += s3b - s3a; tSc += tile_end ? 1 : 0;
 #endif
   };
 #ifdef FU_CONV_STAMPS
   const unsigned long long tL0 = __builtin_amdgcn_s_memtime();
+  tPro = tL0 - tStart;
 #endif
   for (int s = 0; s < T; s += 2) {
     body(std::integral_constant<int, 0>{});
@@ -515,7 +646,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #ifdef FU_CONV_STAMPS
   tLoop = __builtin_amdgcn_s_memtime() - tL0;
 #endif
-  if (!grp) __syncthreads();                                         // group 1's pre-loop barrier
+  if (!grp) wg_barrier();                                            // group 1's pre-loop barrier
   if (wave == 0 && pend) combine();
 #ifdef FU_CONV_STAMPS
   if (P.dbg && lane == 0) {
@@ -523,7 +654,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + wave) * 16;
     d[0] = tM; d[1] = tB1; d[2] = tS; d[3] = tE; d[4] = tB2; d[5] = tLoop; d[6] = __builtin_amdgcn_s_memtime() - tStart;
     d[7] = __builtin_amdgcn_s_memrealtime() - rStart; d[8] = (unsigned long long)T; d[9] = tStart;
-    d[10] = tSd; d[11] = tSw; d[12] = tSc; d[13] = tSv; d[14] = tSl;
+    d[10] = tSd; d[11] = tSw; d[12] = tSc; d[13] = tSv; d[14] = tSl; d[15] = tPro;
   }
 #endif
 }
@@ -533,6 +664,22 @@ bool conv3x3_pp_eligible(const BConvP& P) {
   if ((P.H % 32) != 0) return false;
   const int64_t tiles = (int64_t)P.B * (P.H / 32) * (P.W / 16) * (P.N / 64);
   return tiles >= 8 && tiles < ((int64_t)1 << 24);
+}
+
+// default dispatch: only where every CU gets at least one tile (one workgroup per CU for the whole launch: 128 tiles leave half
+// the chip idle -- 512 -> 256 at 32 x 32 measured 54.8 us against 50.5 on the two-workgroup kernel)
+bool conv3x3_pp_preferred(const BConvP& P) {
+  const int64_t tiles = (int64_t)P.B * (P.H / 32) * (P.W / 16) * (P.N / 64);
+  return conv3x3_pp_eligible(P) && tiles >= 256;
+}
+
+// ... of a dgrad launch that is asked for the BatchNorm-backward sums of its destination: from 8 chunks on.  The sums are ~450
+// vector instructions per wave and tile in the epilogue, which runs beside the other group's MFMA phase at ~8 cycles per
+// instruction; on the two-chunk 256 x 256 layers that is the kernel's critical path (64 -> 64: 125 us against 114 on the
+// two-workgroup kernel, whose second workgroup covers it); from 256 input channels on it disappears (512 -> 512 at 32 x 32: 63
+// against 74 us).
+bool conv3x3_pp_preferred_bnb(const BConvP& P) {
+  return conv3x3_pp_preferred(P) && P.Cin >= 256;
 }
 
 int launch_conv3x3_pp(BConvP& P, const LaunchOpts& o, hipStream_t s) {
@@ -561,18 +708,28 @@ int launch_conv3x3_pp(BConvP& P, const LaunchOpts& o, hipStream_t s) {
     FU_HIP_CHECK(hipGetDevice(&dev));
     FU_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
-    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
+    const void* ks[5] = {reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<false, false, false>),
+                         reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<false, false, true>),
+                         reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<false, true, false>),
+                         reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<false, true, true>),
+                         reinterpret_cast<const void*>(&k_conv3x3_bf16_pp<true, false, false>)};
+    for (const void* k : ks) FU_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES));
   }
   // one workgroup per CU, a multiple of 8 (the XCD of a workgroup's virtual block ids must not change from tile to tile)
   int grid = P.nTiles < n_cu ? P.nTiles : n_cu;
+#ifdef FU_EXPERIMENTS     // variant builds only: a smaller grid leaves CUs to the weight-gradient stream
+  { static const int cap = [] { const char* e = getenv("FU_PP_GRID"); return e ? atoi(e) : 0; }(); if (cap > 0 && grid > cap && (P.bias == nullptr && P.stats == nullptr)) grid = cap; }
+#endif
   grid &= ~7;
   const ProfSlot ps = o.prof;
   if (ps.start) (void)hipEventRecord(ps.start, s);
-  if (P.bnb_y != nullptr) hipLaunchKernelGGL(k_conv3x3_bf16_pp<true>, dim3(grid), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
-  else hipLaunchKernelGGL(k_conv3x3_bf16_pp<false>, dim3(grid), dim3(Cfg::NT), Cfg::SMEM_BYTES, s, P);
+  const bool fwd = P.bias != nullptr || P.stats != nullptr, bn = P.a0 != nullptr;
+  const dim3 g(grid), b(Cfg::NT);
+  if (P.bnb_y != nullptr) hipLaunchKernelGGL((k_conv3x3_bf16_pp<true, false, false>), g, b, Cfg::SMEM_BYTES, s, P);
+  else if (bn && fwd) hipLaunchKernelGGL((k_conv3x3_bf16_pp<false, true, true>), g, b, Cfg::SMEM_BYTES, s, P);
+  else if (bn) hipLaunchKernelGGL((k_conv3x3_bf16_pp<false, true, false>), g, b, Cfg::SMEM_BYTES, s, P);
+  else if (fwd) hipLaunchKernelGGL((k_conv3x3_bf16_pp<false, false, true>), g, b, Cfg::SMEM_BYTES, s, P);
+  else hipLaunchKernelGGL((k_conv3x3_bf16_pp<false, false, false>), g, b, Cfg::SMEM_BYTES, s, P);
   if (ps.stop) (void)hipEventRecord(ps.stop, s);
   FU_LAUNCH_CHECK();
   return 0;

@@ -67,6 +67,20 @@ def from_nhwc(x):
 def forced_rs():
     lib = _lib.load()
     lib.fu_test_conv_tile_mode(3)
+    lib._forced_mode = 3
+    yield lib
+    lib.fu_test_conv_tile_mode(0)
+    lib.fu_test_bnb_separate(0)
+    lib.fu_test_perturb_bnb_sums(1.0)
+
+
+@pytest.fixture
+def forced_pp():
+    """The persistent ping-pong kernel (fu_conv_pp.hip) wherever a launch is eligible (>= 8 tiles of 16 x 32 pixels, H % 32 ==
+    0); by default it is dispatched from 256 tiles on, i.e. never at fixture sizes."""
+    lib = _lib.load()
+    lib.fu_test_conv_tile_mode(4)
+    lib._forced_mode = 4
     yield lib
     lib.fu_test_conv_tile_mode(0)
     lib.fu_test_bnb_separate(0)
@@ -79,7 +93,18 @@ def forced_rs():
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c8_64_b2", "f_full_c8_32"])
 def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced_rs):
-    lib = forced_rs
+    _forced_step_against_reference_fixture(name, prec, forced_rs)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c8_64_b2"])
+def test_forced_pingpong_step_against_reference_fixture(name, prec, forced_pp):
+    """The same whole-net check with the persistent ping-pong kernel on every eligible layer (the 64 x 64 and 32 x 32 levels of
+    these fixtures; the rest falls back to the default kernels)."""
+    _forced_step_against_reference_fixture(name, prec, forced_pp)
+
+
+def _forced_step_against_reference_fixture(name, prec, lib):
     meta, z = load_golden(name)
     batch, st = case_inputs(meta)
     ii = meta["resolved_ignore_index"]
@@ -132,7 +157,7 @@ def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced
     loss_d = net.loss(x, t, ii)
     loss_d.backward()
     torch.cuda.synchronize()
-    lib.fu_test_conv_tile_mode(3)
+    lib.fu_test_conv_tile_mode(lib._forced_mode)
     cos_d = []
     for j, (k, p) in enumerate(net.named_parameters()):
         if not is_dead_bias(k) and p.numel() >= 64 and z["grad_stats1"][j][2] >= 1e-5:
@@ -216,6 +241,100 @@ def test_row_stationary_dgrad_fused_bn_backward_sums(shape, prec, forced_rs):
     assert rel(dx, gref) < lw["eps"]
     assert rel(s1, s1_ref) <= 1e-4, rel(s1, s1_ref)
     assert rel(s2, s2_ref) <= 1e-4, rel(s2, s2_ref)
+
+
+# the persistent ping-pong kernel accumulates every output element in the row-stationary kernel's order (chunk, column shift,
+# kernel row) and sums its statistics in rs<8>'s order: same bits.  B, C0, C1, Cout, H, W, BatchNorm prologue
+PP_FWD = [(2, 64, 0, 64, 64, 48, True), (2, 32, 32, 128, 32, 32, True), (16, 64, 64, 64, 128, 128, True),
+          (16, 256, 256, 256, 32, 32, True), (8, 96, 0, 64, 32, 16, False), (16, 128, 0, 256, 64, 64, False),
+          (4, 512, 0, 512, 32, 32, True)]
+PP_DGRAD = [(2, 64, 64, 0, 64, 32), (16, 64, 64, 64, 128, 128), (4, 512, 512, 512, 32, 32), (16, 256, 128, 128, 64, 64)]
+PP_SUMS = [(4, 64, 64, 128, 128), (8, 128, 128, 64, 64), (2, 256, 192, 32, 32), (2, 64, 64, 64, 32)]
+
+
+def _bits(t):
+    return t.view(torch.int32) if t.dtype == torch.float32 else t.view(torch.int16)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_pingpong_kernel_is_bit_identical_to_row_stationary(prec):
+    """Forward (BatchNorm prologue, two sources, bias, statistics), dgrad (two destinations) and dgrad with the fused
+    BatchNorm-backward sums: tile mode 4 against tile mode 3 on the same operands.  Outputs always bit for bit; the statistics /
+    sums bit for bit where mode 3 runs rs<8> (>= 512 of its tall tiles: the same statistics tiles), to 1e-5 where it runs rs<4>."""
+    lib = _lib.load()
+    lw = LOWP[prec]
+    dt, code = lw["dt"], lw["code"]
+
+    def both(run):
+        outs = []
+        try:
+            for m in (3, 4):
+                lib.fu_test_conv_tile_mode(m)
+                outs.append(run())
+                torch.cuda.synchronize()
+        finally:
+            lib.fu_test_conv_tile_mode(0)
+        return outs
+
+    def compare(outs, tall, what):
+        assert torch.isfinite(outs[1][0].float()).all(), what
+        assert torch.equal(_bits(outs[0][0]), _bits(outs[1][0])), what
+        for p, q in zip(outs[0][1:], outs[1][1:]):
+            if p.dtype != torch.float32:
+                assert torch.equal(_bits(p), _bits(q)), what
+            elif tall:
+                assert torch.equal(_bits(p), _bits(q)), what
+            else:
+                assert ((p - q).abs() <= 1e-5 * (p.abs().max() + 1)).all(), what
+
+    for sh in PP_FWD:
+        B, C0, C1, Cout, H, W, bn = sh
+        g = torch.Generator().manual_seed(0)
+        x0 = torch.randn(B, H, W, C0, generator=g).to(DEV).to(dt)
+        x1 = torch.randn(B, H, W, C1, generator=g).to(DEV).to(dt) if C1 else None
+        a = (torch.rand(C0, generator=g) + 0.5).to(DEV)
+        b = (torch.randn(C0, generator=g) * 0.1).to(DEV)
+        w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 10).to(DEV)
+        bias = torch.randn(Cout, generator=g).to(DEV)
+
+        def run():
+            y = torch.full((B, H, W, Cout), float("nan"), device=DEV, dtype=dt)
+            ssum, ssq = torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
+            check(lib.fu_op_conv3x3_fwd(code, ptr(x0), C0, ptr(a) if bn else None, ptr(b) if bn else None, ptr(x1) if C1 else None,
+                                        C1, ptr(w), ptr(bias), ptr(y), Cout, B, H, W, ptr(ssum), ptr(ssq), stream()))
+            return y, ssum, ssq
+        compare(both(run), B * (H // 32) * (W // 16) * (Cout // 64) >= 512, ("fwd", sh))
+    for sh in PP_DGRAD:
+        B, Cout, C0, C1, H, W = sh
+        g = torch.Generator().manual_seed(1)
+        dy = torch.randn(B, H, W, Cout, generator=g).to(DEV).to(dt)
+        w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / 3).to(DEV)
+
+        def run():
+            dx0 = torch.full((B, H, W, C0), float("nan"), device=DEV, dtype=dt)
+            dx1 = torch.full((B, H, W, C1), float("nan"), device=DEV, dtype=dt) if C1 else None
+            check(lib.fu_op_conv3x3_dgrad(code, ptr(dy), Cout, ptr(w), ptr(dx0), C0, ptr(dx1) if C1 else None, C1, B, H, W,
+                                          stream()))
+            return (dx0,) + ((dx1,) if C1 else ())
+        compare(both(run), True, ("dgrad", sh))
+    for sh in PP_SUMS:
+        B, Cout, C0, H, W = sh
+        g = torch.Generator().manual_seed(2)
+        dy = torch.randn(B, H, W, Cout, generator=g).to(DEV).to(dt)
+        w = (torch.randn(Cout, C0, 3, 3, generator=g) / (3.0 * Cout ** 0.5)).to(DEV)
+        yv = torch.randn(B, H, W, C0, generator=g).to(DEV).to(dt)
+        a = (torch.rand(C0, generator=g) + 0.5).to(DEV)
+        b = (torch.randn(C0, generator=g) * 0.3).to(DEV)
+        mean = (torch.randn(C0, generator=g) * 0.1).to(DEV)
+        invstd = (torch.rand(C0, generator=g) + 0.5).to(DEV)
+
+        def run():
+            dx = torch.full((B, H, W, C0), float("nan"), device=DEV, dtype=dt)
+            s1, s2 = torch.empty(C0, device=DEV), torch.empty(C0, device=DEV)
+            check(lib.fu_op_conv3x3_dgrad_bnsums(code, ptr(dy), Cout, ptr(w), ptr(dx), C0, ptr(yv), ptr(a), ptr(b), ptr(mean),
+                                                 ptr(invstd), ptr(s1), ptr(s2), B, H, W, stream()))
+            return dx, s1, s2
+        compare(both(run), B * (H // 32) * (W // 16) * (C0 // 64) >= 512, ("dgrad + sums", sh))
 
 
 def _head_bwd(lib, lw, seed=3):

@@ -185,6 +185,10 @@ BF_SHAPES = [
     # two sources, two destinations (dgrad), several channel tiles, one and many K chunks
     (2, 64, 0, 64, 64, 48, True),
     (1, 64, 64, 128, 96, 32, True),
+    # ... and the persistent ping-pong kernel (the same + H % 32 == 0, >= 8 tiles): odd step counts (3 chunks), more tiles
+    # than workgroups on a small grid, two sources switching inside a tile, a second destination
+    (3, 96, 0, 64, 64, 32, False),
+    (4, 64, 64, 128, 64, 64, True),
     (2, 128, 64, 64, 32, 16, True),
     (1, 256, 0, 192, 32, 32, False),
     (3, 32, 0, 64, 160, 80, True),
@@ -222,13 +226,14 @@ def nchw_bf(x):
     return x.float().permute(0, 3, 1, 2).contiguous().cpu()
 
 
-@pytest.fixture(params=["auto", "general", "tall", "square", "rs"])
+@pytest.fixture(params=["auto", "general", "tall", "square", "rs", "pp"])
 def conv_path(request):
-    """bf16 forward/dgrad have an aligned-shape fast kernel (16x16 and tall 16x32 workgroup tiles) and a general one:
-    run every shape on all of them."""
+    """bf16 forward/dgrad have an aligned-shape fast kernel (16x16 and tall 16x32 workgroup tiles), a general one, the
+    row-stationary kernel ("rs") and the persistent ping-pong kernel ("pp": forced wherever the shape is eligible, i.e. from 8
+    tiles of 16 x 32 pixels x 64 channels on -- the default dispatch asks for 256): run every shape on all of them."""
     lib = _lib.load()
     lib.fu_test_force_general_conv(1 if request.param == "general" else 0)
-    lib.fu_test_conv_tile_mode({"tall": 2, "square": 1, "rs": 3}.get(request.param, 0))
+    lib.fu_test_conv_tile_mode({"tall": 2, "square": 1, "rs": 3, "pp": 4}.get(request.param, 0))
     yield request.param
     lib.fu_test_force_general_conv(0)
     lib.fu_test_conv_tile_mode(0)
