@@ -1150,8 +1150,9 @@ int fu_destroy(fu_ctx* c) {
   if (c->side) {
     if (c->side_lo) (void)hipStreamDestroy(c->side_lo);
     if (c->side_def) (void)hipStreamDestroy(c->side_def);
-    for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk, c->ev_fence[0], c->ev_fence[1]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_gy, c->ev_wg[0], c->ev_wg[1], c->ev_blk}) if (e) (void)hipEventDestroy(e);
   }
+  for (hipEvent_t e : c->ev_fence) if (e) (void)hipEventDestroy(e);   // (fu_backward_fence creates them without a side stream too)
   if (c->arena.base) (void)hipFree(c->arena.base);
   for (void* p : c->extra_allocs) (void)hipFree(p);
   delete c;

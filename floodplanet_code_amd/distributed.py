@@ -170,15 +170,30 @@ class DataParallelTrainer:
         buf = (C.c_float * 7)()
         _lib.check(_lib.load().fu_adam_scalars(float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                                int(step), 1.0, buf))
-        self._gscal_host.copy_(torch.tensor(list(buf), dtype=torch.float32))
-        self._gscal.copy_(self._gscal_host, non_blocking=True)       # ordered on the current stream, ahead of the replay
+        # A ring of pinned slots, each guarded by an event recorded behind its host-to-device copy: nothing in a replayed step
+        # synchronises, so the host runs steps ahead of the GPU, and ONE pinned buffer would be rewritten for step k+1, k+2, ...
+        # before the copy of step k has executed (the replay of step k would then take a later step's bias corrections).
+        slot = step % len(self._gscal_ring)
+        host, ev = self._gscal_ring[slot], self._gscal_ev[slot]
+        if ev is not None:
+            ev.synchronize()                                          # the copy that last read this slot has executed
+        host.copy_(torch.tensor(list(buf), dtype=torch.float32))
+        self._gscal.copy_(host, non_blocking=True)                    # ordered on the current stream, ahead of the replay
+        ev = torch.cuda.Event()
+        ev.record()
+        self._gscal_ev[slot] = ev
 
     def _capture(self, x, target, ignore_index):
         from . import _lib
         net, dev = self.net, x.device
-        self._gx, self._gt, self._g_ignore = x, target, int(ignore_index)
+        # private static buffers: capturing the caller's first batch in place would overwrite it on every later step (and skip
+        # the copy -- i.e. train on the previous batch -- whenever that first tensor came round again)
+        self._gx, self._gt, self._g_ignore = torch.empty_like(x), torch.empty_like(target), int(ignore_index)
+        self._gx.copy_(x)
+        self._gt.copy_(target)
         self._gscal = torch.zeros(7, dtype=torch.float32, device=dev)
-        self._gscal_host = torch.zeros(7, dtype=torch.float32).pin_memory()
+        self._gscal_ring = [torch.zeros(7, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self._gscal_ev = [None] * 8
         lib = _lib.load()
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
@@ -198,17 +213,15 @@ class DataParallelTrainer:
             if net._ctx is None or net._ctx_key[1:3] != tuple(x.shape[2:]) or net._ctx_key[3] < x.shape[0]:
                 return None                                           # no context for this shape yet: one eager step first
             self._capture(x.detach().contiguous().float(), target.contiguous().long(), ignore_index)
-        if x.data_ptr() != self._gx.data_ptr():
-            self._gx.copy_(x)
-        if target.data_ptr() != self._gt.data_ptr():
-            self._gt.copy_(target)
+        self._gx.copy_(x)
+        self._gt.copy_(target)
         self.step_count += 1
         self._adam_scalars_to_device(self.step_count)
         self._graph.replay()
         net._generation += 1
         net._eval_dirty = True
         net.attach_grads()
-        return self._gloss
+        return self._gloss.clone()       # (the graph's own loss tensor is rewritten by the next replay)
 
     def step(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int) -> torch.Tensor:
         from . import _lib

@@ -360,7 +360,14 @@ def test_full_size_properties(prec):
             elif p.dim() == 4:
                 assert rel(gv5, gv1) <= 0.35, (k, rel(gv5, gv1))
         assert seen == len(tight)
-        assert not torch.equal(g5, g1)          # the two routes are really different code
+        # the two routes are really different code -- unless the environment has forced the alternate route on BOTH runs
+        # (FU_BNB_SEPARATE=1 / FU_HEAD_STORE_G=1 switch the library's dispatch globally: round 3's `r3_alt1` / `r3_alt2` runs
+        # of the whole GPU suite under those two settings; then the comparison is of one route with itself)
+        import os
+        if os.environ.get("FU_BNB_SEPARATE") == "1" or os.environ.get("FU_HEAD_STORE_G") == "1":
+            print("routes forced equal by the environment: 'routes differ' assertion skipped")
+        else:
+            assert not torch.equal(g5, g1)
     net.eval()
     with torch.no_grad():
         full = net(x)
@@ -491,6 +498,39 @@ def test_captured_hipgraph_step_equals_eager_step(prec):
     assert la == lb
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ra, rb) and torch.equal(na, nb_) and torch.equal(ga, gb)
     assert int(na[0]) == 6
+
+
+def test_captured_step_keeps_callers_batches_and_unsynchronised_scalars():
+    """(1) the captured step owns private input buffers -- a retained list of device batches cycled through
+    graph=True must stay unmodified and train exactly as the eager trainer does (the first version captured the caller's first
+    batch in place: later steps overwrote it, and skipped the copy when that tensor came round again); (2) no host
+    synchronisation between steps: the Adam scalars of step k must not be overwritten by later steps before their copy has
+    executed (a ring of pinned slots guarded by events); (3) the returned losses are tensors of their own (collected and
+    read at the end, as a logger does)."""
+    from floodplanet_code_amd.distributed import DataParallelTrainer
+    st = O.make_state(8, 3, 16, True, seed=7)
+    host = [O.make_batch(2, 8, 64, 64, seed=70 + i) for i in range(3)]
+    outs = []
+    for graph in (False, True):
+        net = HipUNet(8, 3, base_channels=16, precision="bf16")
+        net.load_state_dict(st)
+        net.to(DEV).train()
+        tr = DataParallelTrainer(net, lr=1e-2, graph=graph)
+        dev_batches = [(b["image"].to(DEV).contiguous().float(), b["target"].to(DEV).contiguous().long()) for b in host]
+        keep = [(x.clone(), t.clone()) for x, t in dev_batches]
+        losses = []
+        for it in range(12):                       # 12 steps > the 8 slots of the scalar ring, no .item() in between
+            x, t = dev_batches[it % 3]
+            losses.append(tr.step(x, t, 0))
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        for (x, t), (kx, kt) in zip(dev_batches, keep):
+            assert torch.equal(x, kx) and torch.equal(t, kt)          # the caller's batches are untouched
+        outs.append(([l.item() for l in losses], net.flat_parameters().clone(), net.adam_state()[0].clone()))
+    (la, pa, ma), (lb, pb, mb) = outs
+    assert len(set(lb)) > 1                         # twelve different losses, not twelve views of the last one
+    assert la == lb
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
 
 
 def test_backward_of_a_stale_forward_raises():
