@@ -44,10 +44,13 @@ def parse(argv=None):
                     help="unet = the headline workload (ms_model / ef_model); lf = the late-fusion net (lf_model.py): "
                          "--channels image bands + --aux one-band auxiliary inputs, one encoder each")
     ap.add_argument("--aux", type=int, default=1, help="--model lf: number of one-band auxiliary inputs (dem, slope, ...)")
-    ap.add_argument("--path", default="cabi", choices=["cabi", "plugin"],
+    ap.add_argument("--path", default="cabi", choices=["cabi", "plugin", "loader"],
                     help="cabi = DataParallelTrainer over the C ABI (fused fwd+CE, block-wise bwd, fused Adam); plugin = what "
                          "a fit.py user runs: build_model('ms_model') -> configure_optimizers() -> opt.zero_grad(); "
-                         "training_step(); loss.backward(); opt.step() (N=1 only)")
+                         "training_step(); loss.backward(); opt.step() (N=1 only); loader = the DATA path alone (not part of "
+                         "`value`): tiles/s of TileLoader over a synthetic Sentinel-1 tree whose image rasters are smaller than "
+                         "their label rasters (so the Lanczos-4 resample runs), host resample against device resample")
+    ap.add_argument("--loader-workers", type=int, default=4, help="--path loader: DataLoader workers (fit.py's n_workers: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-miou", action="store_true", help="skip the small HIP-vs-oracle training comparison (miou_vs_ref)")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-forward / stitching side measurement")
@@ -368,6 +371,39 @@ class _PluginStepper:
         return loss.detach()
 
 
+def loader_bench(args, dev):
+    """The data path of SURVEY 8(f) ranks 1 / 4 measured alone: FloodplanetTiles (TIFF decode, 360 -> 1024 Lanczos-4 resample,
+    256 x 256 crops, S1 scaling) -> TileLoader(device_assembly=True, transforms={}) -> batches of 16 augmented tiles in HBM.
+    `resize: host` = the per-raster resample in the DataLoader workers (cached per raster; the reference resamples per item,
+    st_water_seg/datasets/floodplanet.py:338-340); `resize: device` = window cut-out in the workers + fu_resize_lanczos4_tiles."""
+    import tempfile, time, torch
+    from floodplanet_code_amd.datasets import FloodplanetTiles, TileLoader, generate_image_slice_object
+    from floodplanet_code_amd.datasets.synthetic import make_s1_tree
+    root = tempfile.mkdtemp(prefix="fu_loader_")
+    n_img = make_s1_tree(root, images_per_region=8, label_size=1024, s1_size=360)
+    sp = generate_image_slice_object(args.size, args.size, args.size)
+    ds = FloodplanetTiles(root, "train", sp, eval_region=["RegC"], sensor="S1", ignore_index=0)
+    out = {"workload": f"synthetic CSDAP tree: {n_img} Sentinel-1 rasters 2 x 360 x 360 f32 -> labels 1024 x 1024 u8, "
+                       f"{len(ds)} tiles of {args.size} x {args.size}, batch {args.batch}, shuffle, hflip / vflip / rotate on "
+                       "the device", "workers": args.loader_workers, "batch": args.batch, "cores": host_cores()}
+    for mode in ("host", "device"):
+        ld = TileLoader(ds, args.batch, dev, shuffle=True, seed=0, drop_last=True, num_workers=args.loader_workers,
+                        transforms={}, ignore_index=0, device_assembly=True, device_resize=(mode == "device"))
+        n, t0 = 0, None
+        for ep in range(3):                      # epoch 0 = warm-up (worker start, page cache, first kernels)
+            if ep == 1:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            for b in ld:
+                if ep >= 1:
+                    n += b["image"].shape[0]
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out[f"tiles_per_s_resize_{mode}"] = round(n / dt, 1)
+        del ld
+    return out
+
+
 def main():
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
@@ -392,6 +428,14 @@ def main():
     n_dev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(1, n_dev))  # (ranks share a device only in the gloo rehearsal)
     torch.cuda.set_device(dev)
+
+    if args.path == "loader":
+        if world > 1:
+            raise SystemExit("--path loader measures one process's data path")
+        res = loader_bench(args, dev)
+        print(json.dumps({"metric": "data-path tiles/sec (not the training metric)", "unit": "tiles/s", "n_gpus": 1,
+                          "data_path": res, "higher_is_better": True}))
+        return
 
     import torch.distributed as dist
     backend = None

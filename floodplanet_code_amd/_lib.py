@@ -84,6 +84,7 @@ SIGNATURES = {
     "fu_stitch_add": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fu_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "fu_augment": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _p]),
+    "fu_resize_lanczos4_tiles": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "fu_assemble_tiles": (_i, [C.POINTER(_p), C.POINTER(C.c_int32), _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p]),
     "fu_workspace_bytes": (_i64, [_p]),
     "fu_flops_per_tile": (_i, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

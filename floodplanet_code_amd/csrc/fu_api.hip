@@ -1533,6 +1533,14 @@ int fu_assemble_tiles(const float* const* srcs, const int32_t* src_channels, int
                                pad_value, out, mean_out, std_out, (hipStream_t)stream);
 }
 
+int fu_resize_lanczos4_tiles(const float* windows, int B, int C, int win_h, int win_w, const int32_t* iy, const float* wy,
+                             const int32_t* ix, const float* wx, int tile_h, int tile_w, int scale_mode, float* out,
+                             fu_stream stream) {
+  FU_REQUIRE(windows && iy && wy && ix && wx && out && B >= 1 && C >= 1, "fu_resize_lanczos4_tiles: bad argument");
+  return launch_resize_lanczos4_tiles(windows, B, C, win_h, win_w, iy, wy, ix, wx, tile_h, tile_w, scale_mode, out,
+                                      (hipStream_t)stream);
+}
+
 // ---- data-parallel collective behind the C ABI (fu_allreduce_begin / wait) ----------------------------------
 // RCCL is resolved at run time (dlopen): the library has no link-time dependency on it, a process that never calls
 // fu_dp_init never loads it, and inside a torch process the copy torch already loaded is the one that is used.

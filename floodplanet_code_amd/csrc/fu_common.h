@@ -413,6 +413,8 @@ int launch_stitch_finalize(float* canvas, const float* weight, int ncls, int64_t
 int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int n_src, int B, int H, int W, const int* vh,
                           const int* vw, int norm_mode, const float* gmean, const float* gstd, float pad_value, float* out,
                           float* mean_out, float* std_out, hipStream_t s);
+int launch_resize_lanczos4_tiles(const float* win, int B, int C, int win_h, int win_w, const int* iy, const float* wy,
+                                 const int* ix, const float* wx, int TH, int TW, int scale_mode, float* out, hipStream_t s);
 int launch_augment(const float* img, const int64_t* tgt, float* img_o, int64_t* tgt_o, const int* flags,
                    const float* angle, int B, int C, int H, int W, int64_t target_fill, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

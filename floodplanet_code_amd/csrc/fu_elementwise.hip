@@ -2039,6 +2039,64 @@ __global__ void k_assemble_tiles(SrcList S, int Ctot, int H, int W, const int* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Lanczos-4 resampling of a batch of tiles (round 4).  The reference resamples the WHOLE raster to the
+// label raster's size for every item it loads (floodplanet.py:338-340 -> utils_image.py:11-54, cv2.INTER_LANCZOS4) and then cuts
+// the tile out.  Lanczos is local: tile rows [Y0, Y0 + TH) of the resampled raster depend on a window of ~TH * scale + 8 source
+// rows, so the host ships that window and two 8-tap tables per tile axis (index into the window, weight) and the device computes
+//     out[b][c][y][x] = sum_kx wx[b][x][kx] * ( sum_ky wy[b][y][ky] * win[b][c][iy[b][y][ky]][ix[b][x][kx]] )
+// in fp32 with the taps accumulated in order and multiply / add rounded separately -- the arithmetic of the numpy restatement
+// (datasets/resize.py: rows first, then columns), so the tile equals the crop of the host's whole-raster result bit for bit.
+// scale_mode = the sensor scaling that follows the crop in the reference (floodplanet.py:347 / :406 / :467 / :525).
+// One thread per output pixel; the window (a few KB per tile and band) is served from L2.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_lanczos4_tiles(const float* __restrict__ win, int C, int win_h, int win_w,
+                                                               const int* __restrict__ iy, const float* __restrict__ wy,
+                                                               const int* __restrict__ ix, const float* __restrict__ wx,
+                                                               int TH, int TW, int scale_mode, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int bc = blockIdx.z, b = bc / C;
+  if (x >= TW || y >= TH) return;
+  const float* w = win + (size_t)bc * win_h * win_w;
+  const int* iyb = iy + ((size_t)b * TH + y) * 8;
+  const float* wyb = wy + ((size_t)b * TH + y) * 8;
+  const int* ixb = ix + ((size_t)b * TW + x) * 8;
+  const float* wxb = wx + ((size_t)b * TW + x) * 8;
+  int ry[8], cx[8];
+  float fy[8], fx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { ry[k] = iyb[k] * win_w; fy[k] = wyb[k]; cx[k] = ixb[k]; fx[k] = wxb[k]; }
+  float o = 0.f;
+#pragma unroll
+  for (int kx = 0; kx < 8; ++kx) {
+    float t = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 8; ++ky) {
+      const float p = fy[ky] * w[ry[ky] + cx[kx]];      // (two roundings: numpy multiplies, then adds)
+      t = t + p;
+    }
+    const float q = fx[kx] * t;
+    o = o + q;
+  }
+  if (scale_mode == 1) o = fminf(fmaxf((o + 50.f) / 100.f, 0.f), 1.f);            // S1 (dB): clip((x + 50) / 100, 0, 1), NaN -> 0
+  else if (scale_mode == 2) o = fminf(fmaxf(o / 4096.f, 0.f), 1.f);                // S2: clip(x / 2^12, 0, 1)
+  else if (scale_mode == 3) o = fminf(fmaxf(o, 0.f), 18607.72f) / 18607.72f;       // L8: clip(x, 0, 18607.72) / 18607.72
+  else if (scale_mode == 4) o = o / 65536.f;                                       // PS stored as uint16: x / 2^16
+  out[((size_t)bc * TH + y) * TW + x] = o;
+}
+
+int launch_resize_lanczos4_tiles(const float* win, int B, int C, int win_h, int win_w, const int* iy, const float* wy,
+                                 const int* ix, const float* wx, int TH, int TW, int scale_mode, float* out, hipStream_t s) {
+  FU_REQUIRE((int64_t)B * C <= 65535 && TH >= 1 && TW >= 1 && win_h >= 1 && win_w >= 1, "resize_lanczos4_tiles: bad shape");
+  FU_REQUIRE(scale_mode >= 0 && scale_mode <= 4, "resize_lanczos4_tiles: scale_mode %d", scale_mode);
+  hipLaunchKernelGGL(k_resize_lanczos4_tiles, dim3(ceil_div(TW, 64), ceil_div(TH, 4), B * C), dim3(256), 0, s, win, C, win_h,
+                     win_w, iy, wy, ix, wx, TH, TW, scale_mode, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("k_resize_lanczos4_tiles launch failed: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
 int launch_assemble_tiles(const float* const* srcs, const int* src_channels, int n_src, int B, int H, int W, const int* vh,
                           const int* vw, int norm_mode, const float* gmean, const float* gstd, float pad_value, float* out,
                           float* mean_out, float* std_out, hipStream_t s) {

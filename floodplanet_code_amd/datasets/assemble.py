@@ -52,3 +52,23 @@ def assemble_tiles(sources: Sequence[torch.Tensor], norm_mode: Optional[str] = N
                                         float(pad_value), ptr(out), ptr(mean) if mode == 1 else None,
                                         ptr(std) if mode == 1 else None, torch.cuda.current_stream(dev).cuda_stream))
     return out, mean.view(B, ctot, 1, 1), std.view(B, ctot, 1, 1)
+
+
+def resize_lanczos4_tiles(windows: torch.Tensor, iy: torch.Tensor, wy: torch.Tensor, ix: torch.Tensor, wx: torch.Tensor,
+                          scale_mode: int = 0) -> torch.Tensor:
+    """C ABI fu_resize_lanczos4_tiles: windows fp32 [B, C, wh, ww] + the tap tables of `resize.lanczos4_axis_window`
+    ([B, TH, 8] / [B, TW, 8]) on a ROCm device -> the resampled (and sensor-scaled) tiles [B, C, TH, TW]."""
+    if windows.device.type != "cuda":
+        raise RuntimeError("resize_lanczos4_tiles runs only on a ROCm GPU; the host restatement is datasets.resize")
+    dev = windows.device
+    win = windows.contiguous().float()
+    iy, ix = (t.to(dev).to(torch.int32).contiguous() for t in (iy, ix))
+    wy, wx = (t.to(dev).float().contiguous() for t in (wy, wx))
+    B, Cc, wh, ww = win.shape
+    TH, TW = iy.shape[1], ix.shape[1]
+    if iy.shape != (B, TH, 8) or wy.shape != (B, TH, 8) or ix.shape != (B, TW, 8) or wx.shape != (B, TW, 8):
+        raise ValueError("tap tables must be [B, tile_h, 8] / [B, tile_w, 8]")
+    out = torch.empty(B, Cc, TH, TW, dtype=torch.float32, device=dev)
+    check(_lib.load().fu_resize_lanczos4_tiles(ptr(win), B, Cc, wh, ww, ptr(iy), ptr(wy), ptr(ix), ptr(wx), TH, TW,
+                                               int(scale_mode), ptr(out), torch.cuda.current_stream(dev).cuda_stream))
+    return out

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .resize import resize_image
+from .resize import lanczos4_axis_window, resize_image
 from .tiff import read_tiff, tiff_size
 from .tiles import CropParams, get_crop_slices
 
@@ -152,6 +152,43 @@ class FloodplanetTiles(torch.utils.data.Dataset):
             image = self._crop(image, crop_params)
         return np.ascontiguousarray(image, dtype=np.float32)
 
+    def _load_raw_raster(self, image_path, channels):
+        """TIFF decode + band selection only (what `_load_norm_raster` does before it resamples): -> (bands-first array in
+        the raster's own resolution and dtype-derived float32, stored-as-uint16 flag).  Cached like the resampled rasters."""
+        key = ("raw", image_path, channels)
+        hit = self._raster_cache.get(key)
+        if hit is not None:
+            return hit
+        image = read_tiff(image_path)
+        s = self.sensor
+        if s == "S1":
+            if image.ndim == 3 and (image.shape[0] > image.shape[1] or image.shape[0] > image.shape[2]):
+                image = np.transpose(image, (2, 0, 1))
+            image = image[:2]
+            if channels != "ALL":
+                raise NotImplementedError(f'No method to subselect S1 images with "{channels}" channel query.')
+        elif s == "PS":
+            image = np.transpose(image, (2, 0, 1))[:4]
+            sel = {"RGB": [2, 1, 0], "RGB_NIR": [2, 1, 0, 3], "ALL": None}
+            if channels not in sel:
+                raise NotImplementedError(f'No method to subselect PS images with "{channels}" channel query.')
+            image = image if sel[channels] is None else image[sel[channels]]
+        elif s == "S2":
+            sel = {"RGB": [3, 2, 1], "RGB_NIR": [3, 2, 1, 7], "ALL": None}
+            if channels not in sel:
+                raise NotImplementedError(f'No method to subselect S2 images with "{channels}" channel query.')
+            image = image if sel[channels] is None else image[sel[channels]]
+        elif s == "L8":
+            if channels != "ALL":
+                raise NotImplementedError(f'No method to subselect L8 images with "{channels}" channel query.')
+        else:
+            raise NotImplementedError(f'No loader for sensor "{s}"')
+        out = (np.ascontiguousarray(image, dtype=np.float32), image.dtype == np.uint16)
+        if len(self._raster_cache) >= 4:
+            self._raster_cache.pop(next(iter(self._raster_cache)))
+        self._raster_cache[key] = out
+        return out
+
     def _load_norm_raster(self, image_path, channels, resize_dims):
         crop_params = None
         image = read_tiff(image_path)
@@ -257,6 +294,67 @@ class FloodplanetTiles(torch.utils.data.Dataset):
         if self.output_metadata:
             out["metadata"] = {"image_path": ex["image_path"], "crop_params": cp, "region_name": ex["region_name"]}
         return out
+
+
+    def window_item(self, index) -> dict:
+        """The example for the DEVICE resampling path (TileLoader(device_resize=True); C ABI fu_resize_lanczos4_tiles): the
+        reference resamples the whole raster to the label raster's size for every item and then crops (floodplanet.py:338-341);
+        here the worker only cuts the window of the SOURCE raster that the tile's rows / columns touch and makes the two
+        8-tap tables -- resampling, sensor scaling, normalisation and padding run on the batch in HBM.  -> window [C, wh, ww],
+        iy / wy [tile_h, 8], ix / wx [tile_w, 8], valid sizes, scale_mode, padded target."""
+        ex = self.dataset[index]
+        cp: CropParams = ex["crop_params"]
+        raster, was_u16 = self._load_raw_raster(ex["image_path"], self.channels)
+        iy, wy, (y0, y1) = lanczos4_axis_window(raster.shape[1], cp.og_height, cp.h0, cp.hE, cp.max_crop_height)
+        ix, wx, (x0, x1) = lanczos4_axis_window(raster.shape[2], cp.og_width, cp.w0, cp.wE, cp.max_crop_width)
+        target = self._load_label_image(ex["label_path"], cp.og_height, cp.og_width, cp)
+        target = self._add_buffer(target, cp.max_crop_height, cp.max_crop_width, constant_value=self.ignore_index)
+        mode = {"S1": 1, "S2": 2, "L8": 3, "PS": 4 if was_u16 else 0}[self.sensor]
+        out = {"window": torch.from_numpy(np.ascontiguousarray(raster[:, y0:y1, x0:x1])),
+               "iy": torch.from_numpy(iy), "wy": torch.from_numpy(wy), "ix": torch.from_numpy(ix), "wx": torch.from_numpy(wx),
+               "valid_hw": (cp.hE - cp.h0, cp.wE - cp.w0), "scale_mode": mode,
+               "target": torch.from_numpy(np.ascontiguousarray(target)).long(),
+               "tile_hw": (cp.max_crop_height, cp.max_crop_width)}
+        if self.output_metadata:
+            out["metadata"] = {"image_path": ex["image_path"], "crop_params": cp, "region_name": ex["region_name"]}
+        return out
+
+
+class WindowTileView(torch.utils.data.Dataset):
+    """FloodplanetTiles seen through window_item (what DataLoader workers produce for the device-side resampling)."""
+
+    def __init__(self, tiles: "FloodplanetTiles"):
+        self.tiles = tiles
+
+    def __len__(self):
+        return len(self.tiles)
+
+    def __getitem__(self, index):
+        return self.tiles.window_item(index)
+
+
+def collate_window_tiles(items: List[dict]) -> dict:
+    """Source windows of one batch in ONE zero-filled host buffer [B, C, wh_max, ww_max] (the tables index from the window's
+    top-left corner, so the filler is never read) + the stacked tap tables, valid sizes and targets."""
+    Cc = items[0]["window"].shape[0]
+    wh = max(i["window"].shape[1] for i in items)
+    ww = max(i["window"].shape[2] for i in items)
+    win = torch.zeros(len(items), Cc, wh, ww, dtype=torch.float32)
+    for b, it in enumerate(items):
+        h, w = it["window"].shape[-2:]
+        win[b, :, :h, :w] = it["window"]
+    modes = {i["scale_mode"] for i in items}
+    if len(modes) != 1:
+        raise ValueError("one sensor scaling per batch")
+    out = {"window": win, "scale_mode": modes.pop(), "tile_hw": items[0]["tile_hw"],
+           "iy": torch.stack([i["iy"] for i in items]), "wy": torch.stack([i["wy"] for i in items]),
+           "ix": torch.stack([i["ix"] for i in items]), "wx": torch.stack([i["wx"] for i in items]),
+           "valid_h": torch.tensor([i["valid_hw"][0] for i in items], dtype=torch.int32),
+           "valid_w": torch.tensor([i["valid_hw"][1] for i in items], dtype=torch.int32),
+           "target": torch.stack([i["target"] for i in items])}
+    if "metadata" in items[0]:
+        out["metadata"] = [i["metadata"] for i in items]
+    return out
 
 
 class RawTileView(torch.utils.data.Dataset):

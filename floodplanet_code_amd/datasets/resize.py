@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["resize_lanczos4", "resize_nearest", "resize_image"]
+__all__ = ["resize_lanczos4", "resize_nearest", "resize_image", "lanczos4_axis_window", "resize_lanczos4_tile"]
 
 
 def _lanczos4_axis(n_src: int, n_dst: int):
@@ -26,6 +26,42 @@ def _lanczos4_axis(n_src: int, n_dst: int):
     w /= w.sum(axis=1, keepdims=True)
     idx = np.clip(x0[:, None].astype(np.int64) + taps[None, :].astype(np.int64), 0, n_src - 1)
     return idx, w.astype(np.float32)
+
+
+def lanczos4_axis_window(n_src: int, n_dst: int, d0: int, d1: int, n_out: int):
+    """Rows [d0, d1) of the axis resampled from n_src to n_dst, for a tile of n_out >= d1 - d0 rows: -> (idx int32 [n_out, 8]
+    relative to the source window, weights fp32 [n_out, 8], (s0, s1) = the window of the source axis the rows touch).  Rows
+    beyond d1 - d0 (a tile at the raster's edge) get zero weights.  n_src == n_dst is the reference's no-op (resize_image
+    returns its input): identity tables (weight 1 on the tap at offset 0), not Lanczos weights of offset 0 (sin(pi k) is not
+    exactly 0).  The device kernel (C ABI fu_resize_lanczos4_tiles) and `resize_lanczos4_tile` consume these tables."""
+    n = d1 - d0
+    if not (0 <= d0 <= d1 <= n_dst and n <= n_out):
+        raise ValueError(f"rows [{d0}, {d1}) of {n_dst} do not fit a tile of {n_out}")
+    idx = np.zeros((n_out, 8), dtype=np.int64)
+    w = np.zeros((n_out, 8), dtype=np.float32)
+    if n_src == n_dst:
+        idx[:n] = np.arange(d0, d1)[:, None]
+        w[:n, 3] = 1.0
+    else:
+        ia, wa = _lanczos4_axis(n_src, n_dst)
+        idx[:n], w[:n] = ia[d0:d1], wa[d0:d1]
+    s0 = int(idx[:n].min()) if n else 0
+    s1 = int(idx[:n].max()) + 1 if n else 1
+    idx[:n] -= s0
+    return idx.astype(np.int32), w, (s0, s1)
+
+
+def resize_lanczos4_tile(window: np.ndarray, iy, wy, ix, wx) -> np.ndarray:
+    """Host restatement of the device kernel: window [C, wh, ww] + the tables of `lanczos4_axis_window` -> [C, TH, TW] =
+    the tile cut out of resize_lanczos4(whole raster) (same taps, same order, fp32: bit for bit)."""
+    a = np.asarray(window, dtype=np.float32)
+    t = np.zeros((a.shape[0], iy.shape[0], a.shape[2]), dtype=np.float32)
+    for k in range(8):
+        t += wy[None, :, k, None] * a[:, iy[:, k], :]
+    out = np.zeros((a.shape[0], iy.shape[0], ix.shape[0]), dtype=np.float32)
+    for k in range(8):
+        out += wx[None, None, :, k] * t[:, :, ix[:, k]]
+    return out
 
 
 def resize_lanczos4(image: np.ndarray, height: int, width: int) -> np.ndarray:

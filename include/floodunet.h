@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FU_ABI_VERSION 4
+#define FU_ABI_VERSION 5
 #define FU_MAX_ENCODERS 6
 
 typedef struct fu_ctx fu_ctx;
@@ -260,6 +260,20 @@ int fu_assemble_tiles(const float* const* srcs, const int32_t* src_channels, int
                       const int32_t* valid_h, const int32_t* valid_w, int norm_mode, const float* global_mean,
                       const float* global_std, float pad_value, float* out, float* mean_out, float* std_out,
                       fu_stream stream);
+
+/* Lanczos-4 resampling of a batch of tiles on the device (ABI 5).  Replaces the per-item WHOLE-RASTER resample of the reference's
+ * loader (st_water_seg/datasets/floodplanet.py:338-340 -> utils/utils_image.py:11-54, cv2.INTER_LANCZOS4) by a per-tile one:
+ * Lanczos is local, so the tile [Y0, Y0 + tile_h) x [X0, X0 + tile_w) of the resampled raster depends only on a window of the
+ * source raster.  windows: fp32 [B][C][win_h][win_w] (the host's cut-outs, padded to a common size); iy / wy: int32 / fp32
+ * [B][tile_h][8], ix / wx: [B][tile_w][8] -- per output row / column the 8 window-relative source indices (borders replicated)
+ * and the normalised Lanczos weights (all-zero rows / columns beyond the raster's edge).  out: fp32 [B][C][tile_h][tile_w] =
+ * the crop of the resampled raster, then the sensor scaling that follows the crop in the reference: scale_mode 0 none, 1 S1
+ * clip((x + 50) / 100, 0, 1) with NaN -> 0 (:347), 2 S2 clip(x / 2^12, 0, 1) (:406), 3 L8 clip(x, 0, 18607.72) / 18607.72 (:525),
+ * 4 PS stored as uint16 x / 2^16 (:467-468).  fp32, taps accumulated in order with separate multiply / add roundings: equal bit
+ * for bit to the host restatement floodplanet_code_amd/datasets/resize.py (OpenCV itself is absent: parity unpinned vs cv2). */
+int fu_resize_lanczos4_tiles(const float* windows, int B, int C, int win_h, int win_w, const int32_t* iy, const float* wy,
+                             const int32_t* ix, const float* wx, int tile_h, int tile_w, int scale_mode, float* out,
+                             fu_stream stream);
 
 /* ---- inference stitching (ImageStitcher_v2, utils/utils_image.py:410-494) ------------- */
 /* canvas[h0:hE, w0:wE, :] += softmax(logits of sample `sample` of the last fu_forward)[:hE-h0, :wE-w0, :];

@@ -20,7 +20,7 @@ def declared_symbols():
 def test_library_exists_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "libfloodunet.so missing: run __graft_entry__.build()"
     lib = _lib.load()
-    assert lib.fu_abi_version() == 4
+    assert lib.fu_abi_version() == 5
 
 
 def test_every_declared_symbol_is_exported_and_bound():

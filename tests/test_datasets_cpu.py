@@ -129,6 +129,45 @@ def tree(tmp_path_factory):
     return root, make_floodplanet_tree(root)
 
 
+def test_lanczos_tile_tables_reproduce_the_crop_of_the_whole_raster():
+    """Round 4: the device resampling path ships per tile a window of the source raster + two 8-tap tables
+    (datasets.resize.lanczos4_axis_window).  Lanczos is local, so the tile computed from them must equal the crop of the whole
+    raster's resample -- bit for bit (same taps, same order) -- for interior tiles, tiles cut at the raster's edge (zero rows
+    beyond it), single rows, upsampling and downsampling; equal sizes give the identity (the reference's resize is a no-op)."""
+    from floodplanet_code_amd.datasets.resize import lanczos4_axis_window, resize_lanczos4, resize_lanczos4_tile
+    g = np.random.default_rng(0)
+    for (hs, ws, hd, wd) in [(37, 41, 128, 96), (120, 90, 50, 64), (33, 33, 33, 70)]:
+        a = g.standard_normal((2, hs, ws)).astype(np.float32)
+        full = resize_lanczos4(a, hd, wd) if (hs, ws) != (hd, wd) else a
+        for (h0, hE, w0, wE, TH, TW) in [(0, 32, 0, 32, 32, 32), (hd - 20, hd, wd - 9, wd, 32, 32), (5, 6, 7, 9, 8, 8),
+                                         (0, min(hd, 48), 0, min(wd, 48), 48, 48)]:
+            iy, wy, (y0, y1) = lanczos4_axis_window(hs, hd, h0, hE, TH)
+            ix, wx, (x0, x1) = lanczos4_axis_window(ws, wd, w0, wE, TW)
+            assert iy.dtype == np.int32 and wy.dtype == np.float32 and iy.min() >= 0 and iy.max() < y1 - y0
+            t = resize_lanczos4_tile(a[:, y0:y1, x0:x1], iy, wy, ix, wx)
+            np.testing.assert_array_equal(t[:, :hE - h0, :wE - w0], full[:, h0:hE, w0:wE])
+            assert not t[:, hE - h0:].any() and not t[:, :, wE - w0:].any()
+    with pytest.raises(ValueError):
+        lanczos4_axis_window(10, 20, 5, 30, 32)
+
+
+def test_window_items_equal_raw_items(tree):
+    """FloodplanetTiles.window_item (device resampling) carries what raw_item (host resampling) computes: resampling the window
+    with its tables and applying the sensor scaling on the host gives raw_item's crop bit for bit, same padded target."""
+    from floodplanet_code_amd.datasets.resize import resize_lanczos4_tile
+    root, _ = tree
+    ds = FloodplanetTiles(root, "all", generate_image_slice_object(40, 40, 40), eval_region=["RegA"], sensor="S1", ignore_index=0)
+    assert len(ds) > 4
+    for i in range(len(ds)):
+        w, r = ds.window_item(i), ds.raw_item(i)
+        t = resize_lanczos4_tile(w["window"].numpy(), w["iy"].numpy(), w["wy"].numpy(), w["ix"].numpy(), w["wx"].numpy())
+        t = np.nan_to_num(np.clip((t + 50) / 100, 0, 1)).astype(np.float32)
+        h, wd = r["raw"].shape[-2:]
+        assert w["valid_hw"] == (h, wd) and w["scale_mode"] == 1
+        np.testing.assert_array_equal(t[:, :h, :wd], r["raw"].numpy())
+        assert torch.equal(w["target"], r["target"])
+
+
 def test_dataset_items_follow_the_reference_contract(tree):
     root, made = tree
     sp = generate_image_slice_object(64, 64, 64)

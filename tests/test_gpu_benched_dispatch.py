@@ -37,10 +37,9 @@ LOWP = {"bf16": dict(code=_lib.FU_BF16, dt=torch.bfloat16, eps=2.0 ** -8),
 # tensor: gradient norm within a factor and cosine (tensors of >= 64 elements whose reference norm is not noise)
 NET_TOL = {"bf16": dict(lmax=0.25, lrms=0.05, loss=0.03, agree=0.93, cos_med=0.9, cos_min=0.75, norm=(0.5, 2.0)),
            "fp16": dict(lmax=0.06, lrms=0.008, loss=0.005, agree=0.99, cos_med=0.97, cos_min=0.95, norm=(0.7, 1.4))}
-# f_full_c8_32 (two 32x32 tiles): the deepest BatchNorms see 2 x 2 x 2 = 8 samples per channel and amplify the bf16 rounding of
-# their inputs the way they amplify fp32 rounding; measured on this fixture, forced dispatch and default
-# dispatch alike: median cosine 0.84, minimum 0.62 (bf16); 0.99 / 0.98 (fp16)
-NET_TOL_SMALL = {"bf16": dict(cos_med=0.78, cos_min=0.5), "fp16": {}}
+# ONE tolerance table for all fixtures.  (Round 3 had a second, wider one for f_full_c8_32: that fixture is B = 1, i.e. FOUR samples
+# per channel at its 2 x 2 level -- a degenerate BatchNorm, median bf16 cosine 0.84 whatever kernel runs -- and proved nothing in
+# 16-bit arithmetic; round 4 replaced it here by f_full_c8_32_b8, the same 32 x 32 full-width net with 32 samples per channel.)
 
 
 def stream():
@@ -91,7 +90,7 @@ def forced_pp():
 # (a) whole net, row-stationary kernel + fused sums forced at fixture size, against the reference fixtures
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c8_64_b2", "f_full_c8_32"])
+@pytest.mark.parametrize("name", ["f_full_c8_64_b8", "f_full_c8_64_b2", "f_full_c8_32_b8"])
 def test_forced_row_stationary_step_against_reference_fixture(name, prec, forced_rs):
     _forced_step_against_reference_fixture(name, prec, forced_rs)
 
@@ -109,8 +108,6 @@ def _forced_step_against_reference_fixture(name, prec, lib):
     batch, st = case_inputs(meta)
     ii = meta["resolved_ignore_index"]
     tol = dict(NET_TOL[prec])
-    if name == "f_full_c8_32":
-        tol.update(NET_TOL_SMALL[prec])
     net = HipUNet(meta["n_in"], 3, base_channels=meta["base"], precision=prec)
     net.load_state_dict(st)
     net.to(DEV).train()

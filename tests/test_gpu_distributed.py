@@ -149,6 +149,36 @@ def test_exact_mode_two_ranks_reproduce_one_device_with_the_joint_batch(tmp_path
     assert d <= 2.5e-3, d      # +-lr sign flips on noise-level gradients
     # and it is NOT what DDP semantics give: per-rank statistics differ visibly on such small batches
 
+    # ... and against the ORACLE (the comparison above is HIP with HIP): the reference arithmetic
+    # (oracle/unet_oracle.py, pinned bit-exactly to the reference's unet.py) on the concatenated 4-tile batch, with the bounds of
+    # tests/test_gpu_unet.py::test_matches_live_oracle -- loss 1e-5, BatchNorm buffers 1e-4, every live gradient tensor within
+    # max(3 x the oracle's own fp32-vs-fp64 error, 3e-2), their median within max(3 x, 1e-2) of an fp64 run of the same graph
+    from conftest import is_dead_bias
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    joint = {"image": torch.cat([b0["image"], b1["image"]]), "target": torch.cat([b0["target"], b1["target"]])}
+    st32 = O.make_state(8, 3, 16, True, seed=0)
+    _, loss_o, g32 = O.loss_and_grads(st32, joint, 0)
+    st64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in O.make_state(8, 3, 16, True, seed=0).items()}
+    _, _, g64 = O.loss_and_grads(st64, {"image": joint["image"].double(), "target": joint["target"]}, 0)
+    assert abs(res["loss"].item() - loss_o.item()) <= 1e-5
+    for name, got in (("running_mean", res["rm"]), ("running_var", res["rv"])):
+        want = torch.cat([v.reshape(-1) for k, v in st32.items() if k.endswith(name)])
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), name
+    e_hip, e_ref = [], []
+    for (k, p, off, n) in net._table:
+        if is_dead_bias(k):
+            continue
+        t64 = g64[k].reshape(-1)
+        if t64.norm().item() < 1e-9:
+            continue
+        eh = ((res["grads"][off:off + n].double() - t64).norm() / t64.norm()).item()
+        er = ((g32[k].reshape(-1).double() - t64).norm() / t64.norm()).item()
+        assert eh <= max(3 * er, 3e-2), (k, eh, er)
+        e_hip.append(eh); e_ref.append(er)
+    import statistics
+    assert len(e_hip) >= 40
+    assert statistics.median(e_hip) <= max(3 * statistics.median(e_ref), 1e-2), (statistics.median(e_hip), statistics.median(e_ref))
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # late fusion (lf_model.py): the same trainer, more blocks (head, up4..up1, fusion, 2 x 5 encoder blocks)

@@ -1046,6 +1046,67 @@ def test_multi_source_input_equals_the_concatenated_input(prec):
         nets[0]([img, dem])                      # 9 channels for a 10-channel model
 
 
+def test_device_lanczos_tiles_equal_the_host_resample_bit_for_bit(tmp_path):
+    """fu_resize_lanczos4_tiles (round 4; reference: the per-item whole-raster cv2.INTER_LANCZOS4 resize of
+    st_water_seg/datasets/floodplanet.py:338-340, utils/utils_image.py:11-54): (a) the kernel on random windows / tables against
+    the numpy restatement of the same taps -- bit for bit, NaN pixels and the S1 / S2 / L8 / PS scalings included; (b) the
+    loader's device-resampling path (window cut-out in the worker, resample + scaling + assembly in HBM) against its
+    host-resampling path (whole-raster resample in the worker) on rasters whose images are smaller than their labels and whose
+    tile grid cuts crops at the raster's edge: identical images for norm_mode None, 3e-6 for 'local' (fp64 statistics on the
+    device), identical targets.  OpenCV itself is absent from the image: parity with cv2 stays unpinned (datasets/resize.py)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from tools.tiff_writer import make_floodplanet_tree
+    from floodplanet_code_amd.datasets import FloodplanetTiles, TileLoader, generate_image_slice_object
+    from floodplanet_code_amd.datasets.assemble import resize_lanczos4_tiles
+    from floodplanet_code_amd.datasets.resize import lanczos4_axis_window, resize_lanczos4, resize_lanczos4_tile
+    g = np.random.default_rng(3)
+    src = (g.random((3, 45, 52), dtype=np.float32) * 70 - 50).astype(np.float32)
+    src[1, 7, 9] = np.nan
+    full = resize_lanczos4(src, 150, 131)
+    tiles = [(0, 64, 0, 64), (64, 128, 64, 128), (128, 150, 67, 131), (100, 150, 120, 131)]
+    wins, tabs = [], []
+    for (h0, hE, w0, wE) in tiles:
+        iy, wy, (y0, y1) = lanczos4_axis_window(45, 150, h0, hE, 64)
+        ix, wx, (x0, x1) = lanczos4_axis_window(52, 131, w0, wE, 64)
+        wins.append(src[:, y0:y1, x0:x1])
+        tabs.append((iy, wy, ix, wx))
+    wh, ww = max(w.shape[1] for w in wins), max(w.shape[2] for w in wins)
+    win = np.zeros((len(tiles), 3, wh, ww), dtype=np.float32)
+    for b, w in enumerate(wins):
+        win[b, :, :w.shape[1], :w.shape[2]] = w
+    stack = lambda k: torch.from_numpy(np.stack([t[k] for t in tabs]))
+    scal = {0: lambda v: v, 1: lambda v: np.nan_to_num(np.clip((v + 50) / 100, 0, 1)), 2: lambda v: np.clip(v / 2 ** 12, 0, 1),
+            3: lambda v: np.clip(v, 0, 18607.72) / 18607.72, 4: lambda v: v / 2 ** 16}
+    for mode, fn in scal.items():
+        got = resize_lanczos4_tiles(torch.from_numpy(win).to(DEV), stack(0), stack(1), stack(2), stack(3), mode).cpu().numpy()
+        for b, (h0, hE, w0, wE) in enumerate(tiles):
+            ref_t = resize_lanczos4_tile(wins[b], *tabs[b])
+            np.testing.assert_array_equal(ref_t[:, :hE - h0, :wE - w0], full[:, h0:hE, w0:wE])      # tile == crop of the whole
+            want = fn(ref_t).astype(np.float32)
+            if mode == 0:
+                np.testing.assert_array_equal(np.isnan(got[b]), np.isnan(want))
+            np.testing.assert_array_equal(np.nan_to_num(got[b]), np.nan_to_num(want), err_msg=f"mode {mode} tile {b}")
+    # (b) the loader
+    root = str(tmp_path / "data")
+    make_floodplanet_tree(root, label_size=150, s1_size=52)
+    sp = generate_image_slice_object(64, 64, 64)
+    for norm_mode in (None, "local"):
+        ds = FloodplanetTiles(root, "all", sp, eval_region=["RegC"], sensor="S1", ignore_index=0, norm_mode=norm_mode)
+        host = TileLoader(ds, 3, DEV, shuffle=False, device_assembly=True)
+        devl = TileLoader(ds, 3, DEV, shuffle=False, device_assembly=True, device_resize=True)
+        n = 0
+        for bh, bd in zip(host, devl):
+            assert bd["image"].device.type == "cuda" and bd["image"].shape == bh["image"].shape
+            if norm_mode is None:
+                assert torch.equal(bh["image"], bd["image"])
+            else:
+                assert (bh["image"] - bd["image"]).abs().max().item() <= 3e-6 * max(1.0, bh["image"].abs().max().item())
+            assert torch.equal(bh["target"], bd["target"])
+            n += bh["image"].shape[0]
+        assert n == len(ds) and n >= 18
+
+
 def test_tiff_tiles_train_through_the_registry(tmp_path):
     """BASELINE configs[0] on rasters in the bundled sample's format (S1: 2-band float32 planar strips, uint8 labels at a
     higher resolution): TIFF decode -> Lanczos resample -> tile grid -> GPU augmentation -> registry model -> fit loop."""
