@@ -52,6 +52,8 @@ def parse(argv=None):
                          "their label rasters (so the Lanczos-4 resample runs), host resample against device resample")
     ap.add_argument("--loader-workers", type=int, default=4, help="--path loader: DataLoader workers (fit.py's n_workers: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loader", action="store_true", help="skip the data-path measurement (`data_path` object; outside the timed "
+                                                                "region, never part of `value`)")
     ap.add_argument("--no-miou", action="store_true", help="skip the small HIP-vs-oracle training comparison (miou_vs_ref)")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-forward / stitching side measurement")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("FU_STEP_GRAPH", "0")), choices=[0, 1],
@@ -371,7 +373,7 @@ class _PluginStepper:
         return loss.detach()
 
 
-def loader_bench(args, dev):
+def loader_bench(args, dev, host_budget=20.0, device_epochs=4):
     """The data path of SURVEY 8(f) ranks 1 / 4 measured alone: FloodplanetTiles (TIFF decode, 360 -> 1024 Lanczos-4 resample,
     256 x 256 crops, S1 scaling) -> TileLoader(device_assembly=True, transforms={}) -> batches of 16 augmented tiles in HBM.
     `resize: host` = the per-raster resample in the DataLoader workers (cached per raster; the reference resamples per item,
@@ -380,7 +382,7 @@ def loader_bench(args, dev):
     from floodplanet_code_amd.datasets import FloodplanetTiles, TileLoader, generate_image_slice_object
     from floodplanet_code_amd.datasets.synthetic import make_s1_tree
     root = tempfile.mkdtemp(prefix="fu_loader_")
-    n_img = make_s1_tree(root, images_per_region=8, label_size=1024, s1_size=360)
+    n_img = make_s1_tree(root, images_per_region=24, label_size=1024, s1_size=360)
     sp = generate_image_slice_object(args.size, args.size, args.size)
     ds = FloodplanetTiles(root, "train", sp, eval_region=["RegC"], sensor="S1", ignore_index=0)
     out = {"workload": f"synthetic CSDAP tree: {n_img} Sentinel-1 rasters 2 x 360 x 360 f32 -> labels 1024 x 1024 u8, "
@@ -389,16 +391,23 @@ def loader_bench(args, dev):
     for mode in ("host", "device"):
         ld = TileLoader(ds, args.batch, dev, shuffle=True, seed=0, drop_last=True, num_workers=args.loader_workers,
                         transforms={}, ignore_index=0, device_assembly=True, device_resize=(mode == "device"))
-        n, t0 = 0, None
-        for ep in range(3):                      # epoch 0 = warm-up (worker start, page cache, first kernels)
-            if ep == 1:
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-            for b in ld:
-                if ep >= 1:
-                    n += b["image"].shape[0]
+        n, t0, it = 0, None, iter(ld)
+        for _ in range(8):                       # warm-up: worker start, page cache, first kernels
+            next(it)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        budget = host_budget if mode == "host" else 1e9   # the host path is ~50x slower: a bounded sample of it
+        for ep in range(device_epochs):
+            for b in it:
+                n += b["image"].shape[0]
+                if time.perf_counter() - t0 > budget:
+                    break
+            if time.perf_counter() - t0 > budget:
+                break
+            it = iter(ld)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        out[f"tiles_timed_resize_{mode}"] = n
         out[f"tiles_per_s_resize_{mode}"] = round(n / dt, 1)
         del ld
     return out
@@ -678,6 +687,11 @@ def main():
             out["eval"] = eval_forward_bench(net, dev, x)
         if world == 1 and not args.no_miou:
             out["miou_vs_ref"] = miou_vs_ref(dev, args.dtype)
+        if world == 1 and not args.no_loader and args.path == "cabi" and args.model == "unet":
+            # the data path beside the train number ("at >= 1,000 tiles/s/GPU the CPU DataLoader starves
+            # the GPU"): tiles/s of TileLoader with the Lanczos-4 resample in the workers / on the device; `--path loader` runs
+            # the longer sample
+            out["data_path"] = loader_bench(args, dev, host_budget=6.0, device_epochs=2)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

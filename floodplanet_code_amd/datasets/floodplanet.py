@@ -145,7 +145,7 @@ class FloodplanetTiles(torch.utils.data.Dataset):
         image = self._raster_cache.get(key)
         if image is None:
             image = self._load_norm_raster(image_path, channels, resize_dims)
-            if len(self._raster_cache) >= 4:
+            if len(self._raster_cache) >= 8:
                 self._raster_cache.pop(next(iter(self._raster_cache)))
             self._raster_cache[key] = image
         if crop_params is not None:
@@ -184,7 +184,7 @@ class FloodplanetTiles(torch.utils.data.Dataset):
         else:
             raise NotImplementedError(f'No loader for sensor "{s}"')
         out = (np.ascontiguousarray(image, dtype=np.float32), image.dtype == np.uint16)
-        if len(self._raster_cache) >= 4:
+        if len(self._raster_cache) >= 8:
             self._raster_cache.pop(next(iter(self._raster_cache)))
         self._raster_cache[key] = out
         return out
@@ -231,9 +231,17 @@ class FloodplanetTiles(torch.utils.data.Dataset):
         return np.ascontiguousarray(image, dtype=np.float32)
 
     def _load_label_image(self, label_path, desired_height, desired_width, crop_params):
-        label = read_tiff(label_path)
-        if label.shape != (desired_height, desired_width):
-            label = resize_image(label, desired_height, desired_width, resize_mode="nearest")
+        # (cached like the image rasters: the reference decodes the whole 1024 x 1024 label raster again for every crop,
+        #  floodplanet.py:557-583 -- with the resampling on the device this decode was what capped the loader)
+        key = ("label", label_path, desired_height, desired_width)
+        label = self._raster_cache.get(key)
+        if label is None:
+            label = read_tiff(label_path)
+            if label.shape != (desired_height, desired_width):
+                label = resize_image(label, desired_height, desired_width, resize_mode="nearest")
+            if len(self._raster_cache) >= 8:
+                self._raster_cache.pop(next(iter(self._raster_cache)))
+            self._raster_cache[key] = label
         label = self._crop(label, crop_params)
         out = np.zeros(label.shape, dtype=np.uint8)          # 1 (no flood) -> 0
         out[label == 2] = 1                                  # flood

@@ -6,6 +6,6 @@ cd $GRAFT_REPO_ROOT
 for l in "$@"; do
   case "$l" in /*) lp="$l" ;; *) lp="$GRAFT_REPO_ROOT/tools/dbglibs/$l" ;; esac
   for r in 1 2; do
-    FU_LIB_PATH="$lp" timeout -k 10 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-miou 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l', d['value'], d['ms_per_step'], d['roofline']['achieved'])" || exit 1
+    FU_LIB_PATH="$lp" timeout -k 10 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-miou --no-loader 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l', d['value'], d['ms_per_step'], d['roofline']['achieved'])" || exit 1
   done
 done

@@ -7,7 +7,7 @@ export FU_NO_SIDE_STREAM=1
 for l in "$@"; do
   export FU_LIB_PATH="$GRAFT_REPO_ROOT/tools/dbglibs/$l"
   rm -rf gpurun_out/abs_$l
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abs_$l -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-serial-pass --no-miou > gpurun_out/abs_$l.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abs_$l -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-serial-pass --no-miou --no-loader > gpurun_out/abs_$l.log 2>&1 || exit 1
   f=$(find gpurun_out/abs_$l -name "*kernel_stats.csv" | head -1)
   python3 - "$f" "$l" <<'PY'
 import csv, sys
