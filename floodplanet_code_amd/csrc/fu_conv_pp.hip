@@ -372,6 +372,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     });
     static_for<0, PD>([&](auto Tc) { ld_p(Par, Tc); });
   };
+  // (Measured and dropped, round 4: the zero-padding mask and the ds_write_b128 of a unit -- a 5-dword LDS store holds the wave's
+  //  issue for ~50 cycles, three MFMA gaps; five of them cost this phase ~245 cycles -- moved out into the idle phase, with group
+  //  1 a whole step ahead so that its rows are complete in time (the first build's schedule).  The MFMA phase of a plain source
+  //  went 2665 -> 2485 cycles, but the stores then run beside the OTHER group's MFMA phase and slow that one down: BatchNorm
+  //  layers 6480 -> 6730 cycles per step, plain two-chunk layers 10030 -> 9720; in the bench step forward + dgrad got 5 % slower.)
   // The MFMA phase of a step (stage Par) + this wave's conversion of the NEXT step's units (set 1 - Par -> stage 1 - Par).
   // Issue rules measured with tools/probes/mfma16_issue_probe.hip: a wave issues one instruction per 4-cycle turn of its SIMD;
   // v_mfma_f32_16x16x32 takes two turns and the matrix pipe 16 cycles, so exactly TWO other instructions of any kind (VALU,
@@ -577,6 +582,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   if constexpr (BN) {
     for (int c = tid; c < P.C0; c += Cfg::NT) { sAB[c] = P.a0[c]; sAB[512 + c] = P.b0[c]; }
   }
+  // (measured, no effect on any layer: s_setprio 1 for the younger half once at kernel start -- MI355X_MICROARCH.md "Two waves per
+  //  SIMD" item 4 --, and s_setprio 1 / 2 around the MFMA phase)
   load_tile(lv);
   dma_tile(dv);
   load_all(std::integral_constant<int, 0>{});                        // step 0 -> set 0
