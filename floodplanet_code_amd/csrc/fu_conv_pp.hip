@@ -376,7 +376,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   //  issue for ~50 cycles, three MFMA gaps; five of them cost this phase ~245 cycles -- moved out into the idle phase, with group
   //  1 a whole step ahead so that its rows are complete in time (the first build's schedule).  The MFMA phase of a plain source
   //  went 2665 -> 2485 cycles, but the stores then run beside the OTHER group's MFMA phase and slow that one down: BatchNorm
-  //  layers 6480 -> 6730 cycles per step, plain two-chunk layers 10030 -> 9720; in the bench step forward + dgrad got 5 % slower.)
+  //  layers 6480 -> 6730 cycles per step, plain two-chunk layers 10030 -> 9720; in the bench step forward + dgrad got 5 % slower.
+  //  Also measured, no change on any layer: each unit as two ds_write_b64 in two different gaps instead of one ds_write_b128.)
   // The MFMA phase of a step (stage Par) + this wave's conversion of the NEXT step's units (set 1 - Par -> stage 1 - Par).
   // Issue rules measured with tools/probes/mfma16_issue_probe.hip: a wave issues one instruction per 4-cycle turn of its SIMD;
   // v_mfma_f32_16x16x32 takes two turns and the matrix pipe 16 cycles, so exactly TWO other instructions of any kind (VALU,

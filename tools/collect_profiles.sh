@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copies the judged summaries of tools/prof_all.sh from gpurun_out/ (scratch) into profiles/ (tracked).  usage: tools/collect_profiles.sh r2
 set -e
-R=${1:-r3}
+R=${1:-r4}
 cd "$(dirname "$0")/.."
 for m in bf16 bf16_serial f16 f32; do
   f=$(ls -t gpurun_out/${R}_ks_${m}/*/*_kernel_stats.csv | head -1)

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 set -e
 mkdir -p gpurun_out
-R=${1:-r3}
+R=${1:-r4}
 python3 bench.py --steps 30 --warmup 5 > gpurun_out/${R}_bench_bf16.json 2> gpurun_out/${R}_bench_bf16.err
 tail -c 2500 gpurun_out/${R}_bench_bf16.json
 python3 bench.py --steps 30 --warmup 5 --dtype f16 --no-cpu-baseline --no-eval > gpurun_out/${R}_bench_f16.json 2> gpurun_out/${R}_bench_f16.err
