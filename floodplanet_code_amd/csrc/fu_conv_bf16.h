@@ -27,6 +27,7 @@
 #define k_conv3x3_bf16_fast k_conv3x3_f16_fast
 #define k_wgrad_bf16 k_wgrad_f16
 #define k_wgrad_bf16_pp k_wgrad_f16_pp
+#define k_wgrad_bf16_c8 k_wgrad_f16_c8
 #define conv3x3_rs_eligible conv3x3_rs_eligible_f16
 #define launch_conv3x3_rs launch_conv3x3_rs_f16
 #define conv3x3_c8_eligible conv3x3_c8_eligible_f16

@@ -1099,6 +1099,249 @@ __global__ __launch_bounds__(512) void k_wgrad_bf16_pp(BWgP P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad of the network's first conv: 8 input channels (the image bands, no BatchNorm in front), 64 output channels
+//
+// On the kernels above this layer pads c_in to a 64-row tile: 7 of 8 MFMA rows multiply zeros, 58-60 us against ~30 us
+// of traffic (134 MB of dy + 17 MB of x).  With 8 channels a pixel of x is ONE 16-byte vector and the whole 3x3 window
+// is M = 72 = 9 taps x 8 channels, so the GEMM is (72 x pixels) . (pixels x 64) and the kernel is a stream over dy:
+//   * MFMA 16x16x32, K = one tile row of 32 pixels; M tile j = taps 2j, 2j + 1 (the fifth holds tap 8 twice, its second
+//     half is never stored), N tile s = 16 output channels: 5 x 4 accumulator tiles = 80 registers per wave;
+//   * the 4 waves split K: wave w multiplies tile rows 2w, 2w + 1 (10 + 8 transposing fragment reads per 20 MFMAs) and
+//     the workgroup adds its four partial sums once, at the end, through LDS in a fixed order -- one split-K slab per
+//     workgroup, same slab layout as the other kernels (the reduce / transpose passes are shared);
+//   * dy goes global -> LDS by LDS-DMA (no staging registers, no ds_write): [pixel][64 channels] rows of 128 bytes, the
+//     32-byte segment s of pixel p stored at s ^ (p & 3) ^ ((p >> 3) & 1), which spreads the four (eight) pixels of a
+//     ds_read_b64_tr_b16 lane group over all banks; the swizzle is applied on the SOURCE side (a lane of the DMA picks
+//     its global address, its LDS slot is fixed);
+//   * x ([10][38 px][8 ch]; 38: the one tap pair that straddles two halo rows, (0,2) / (1,0), lands on disjoint banks)
+//     passes through two registers per thread, zeroed off the image;
+//   * two stages of 38 KB, two workgroups per CU; per tile: wait for the own DMA, store x, ONE barrier, issue the next
+//     tile's DMA and loads, multiply.
+// Eligible: C_in = 8 from one un-normalised source, C_out = 64, H % 8 = 0, W % 32 = 0 (launch_conv3x3_wgrad_bf16).
+// ------------------------------------------------------------------------------------------------
+#if FU_HALF
+#define FU_MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
+#define FU_MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+struct WC8 {
+  static constexpr int NT = 256, TH = 8, TW = 32, XRS = 38, XROWS = TH + 2, XCOLS = TW + 2;
+  static constexpr int X_UNITS = XROWS * XCOLS;              // 340 halo pixels of 16 bytes
+  static constexpr int D_BYTES = TH * TW * 128;              // 32768
+  static constexpr int X_BYTES = XROWS * XRS * 16;           // 6080
+  static constexpr int STAGE = D_BYTES + X_BYTES;            // 38848
+  static constexpr int SMEM_BYTES = 2 * STAGE;               // 77696: two workgroups per CU
+  static_assert(3 * 20 * 1024 <= SMEM_BYTES, "the final reduction of three waves' accumulators reuses the stages");
+};
+
+__global__ __launch_bounds__(256, 2) void k_wgrad_bf16_c8(BWgP P) {
+  using C = WC8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int split = blockIdx.x;
+  const int pt0 = split * P.perSplit;
+  const int pt1 = min(P.nPix, pt0 + P.perSplit);
+  const int T = pt1 - pt0;
+  if (T <= 0) return;                                        // (uniform; cannot happen with the launcher's split)
+
+  f32x4w acc[5][4];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[j][s] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses (bytes from the stage base): lane 4q + p of k-group g supplies pixel 8g + q (+ 4 in the second
+  // read) and "channels" 4p .. 4p + 3 of the 16 rows / columns of the operand tile
+  int abase[2][5], bbase[2][4];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tap = min(2 * j + (p >> 1), 8), ky = tap / 3, kx = tap - 3 * ky;
+    abase[0][j] = C::D_BYTES + ((2 * wave + ky) * C::XRS + 8 * g + q + kx) * 16 + 8 * (p & 1);
+    abase[1][j] = abase[0][j] + C::STAGE;
+    asm volatile("" : "+v"(abase[0][j]), "+v"(abase[1][j]));
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bbase[0][s] = (2 * wave * C::TW + 8 * g + q) * 128 + ((s ^ q ^ (g & 1)) * 32) + 8 * p;
+    bbase[1][s] = bbase[0][s] + C::STAGE;
+    asm volatile("" : "+v"(bbase[0][s]), "+v"(bbase[1][s]));
+  }
+
+  // dy DMA: wave-instruction i = 8 wave + it covers pixels 8i .. 8i + 7 of the tile (row i >> 2, columns 8 (i & 3) ..),
+  // lane = (pixel lane >> 3, 16-byte slot lane & 7); the slot holds source unit 2 ((slot >> 1) ^ sw) + (slot & 1),
+  // sw = (pixel & 3) ^ (i & 1)
+  unsigned dlane[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int lp = lane >> 3, sl = lane & 7, sw = (lp & 3) ^ par;
+    dlane[par] = (unsigned)(lp * 128 + (2 * ((sl >> 1) ^ sw) + (sl & 1)) * 16);
+  }
+  // x: halo pixel u = tid (+ 256): byte offset from the tile's origin pixel, border membership, LDS address
+  int xrel[2], xlds[2];
+  unsigned xT = 0, xB = 0, xL = 0, xR = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = min(tid + k * C::NT, C::X_UNITS - 1);
+    const int hy = u / C::XCOLS, hx = u - hy * C::XCOLS;
+    xrel[k] = ((hy - 1) * P.W + (hx - 1)) * 16;
+    xlds[k] = C::D_BYTES + (hy * C::XRS + hx) * 16;
+    xT |= (hy == 0) ? (1u << k) : 0u;  xB |= (hy == C::XROWS - 1) ? (1u << k) : 0u;
+    xL |= (hx == 0) ? (1u << k) : 0u;  xR |= (hx == C::XCOLS - 1) ? (1u << k) : 0u;
+  }
+  const bool x2 = tid + C::NT < C::X_UNITS;                  // this thread owns a second halo pixel
+  const char* xb = reinterpret_cast<const char*>(P.src0);
+  const char* db = reinterpret_cast<const char*>(P.dy);
+  const unsigned rowB = (unsigned)P.W * 128u;
+
+  uint4 rx0, rx1;
+  unsigned xbad = 0;
+  auto issue = [&](int pt, int st) __attribute__((always_inline)) {        // pt, st uniform
+    const int t2 = fast_div(pt, P.tilesX, P.rcp_tilesX);
+    const int tx = pt - t2 * P.tilesX;
+    const int bb = fast_div(t2, P.tilesY, P.rcp_tilesY);
+    const int y0 = (t2 - bb * P.tilesY) * C::TH, x0 = tx * C::TW;
+    const size_t tile_pix = (size_t)((bb * P.H + y0) * P.W + x0);
+    const char* dt = db + tile_pix * 128 + (size_t)(2 * wave) * rowB;
+    unsigned char* ls = smem_raw + st * C::STAGE + wave * 8192;
+    unsigned d0 = dlane[0], d1 = dlane[1];
+    asm volatile("" : "+v"(d0), "+v"(d1));                   // (opaque: see fu_conv_rs.hip, hoisted 64-bit lane addresses)
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(dt + (size_t)(it >> 2) * rowB + (size_t)((it & 3) * 1024) + (size_t)((it & 1) ? d1 : d0)),
+          (__attribute__((address_space(3))) void*)(ls + it * 1024), 16, 0, 0);
+    const unsigned ft = y0 == 0 ? ~0u : 0u, fb = y0 + C::TH == P.H ? ~0u : 0u;
+    const unsigned fl = x0 == 0 ? ~0u : 0u, fr = x0 + C::TW == P.W ? ~0u : 0u;
+    xbad = (xT & ft) | (xB & fb) | (xL & fl) | (xR & fr);
+    const char* xt = xb + tile_pix * 16;
+    rx0 = *reinterpret_cast<const uint4*>(xt + ((xbad & 1u) ? 0 : xrel[0]));   // off the image: the origin pixel, zeroed below
+    rx1 = *reinterpret_cast<const uint4*>(xt + ((xbad & 2u) ? 0 : xrel[1]));
+  };
+  auto store_x = [&](int st) __attribute__((always_inline)) {
+    const unsigned m0 = (xbad & 1u) ? 0u : ~0u, m1 = (xbad & 2u) ? 0u : ~0u;
+    uint4 v0 = rx0, v1 = rx1;
+    v0.x &= m0; v0.y &= m0; v0.z &= m0; v0.w &= m0;
+    v1.x &= m1; v1.y &= m1; v1.z &= m1; v1.w &= m1;
+    *reinterpret_cast<uint4*>(smem_raw + st * C::STAGE + xlds[0]) = v0;
+    if (x2) *reinterpret_cast<uint4*>(smem_raw + st * C::STAGE + xlds[1]) = v1;
+  };
+  // the fragments of both tile rows of this wave are requested BEFORE the next tile's DMA is issued and multiplied after it:
+  // hipcc orders every LDS read behind an outstanding LDS-DMA (s_waitcnt vmcnt) -- reads that follow the issue in program
+  // order would wait for the tile that has just been requested
+  frag8_t Bf[2][4], Af[2][5];
+  auto read_frags = [&](auto Par) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value;
+    static_for<0, 2>([&](auto RR) {
+      constexpr int rr = decltype(RR)::value;
+      static_for<0, 4>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const bf16_t* bd = reinterpret_cast<const bf16_t*>(smem_raw + bbase[par][s] + rr * (C::TW * 128));
+        Bf[rr][s] = tr_frag(bd, bd + 4 * 64);
+      });
+      static_for<0, 5>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const bf16_t* ad = reinterpret_cast<const bf16_t*>(smem_raw + abase[par][j] + rr * (C::XRS * 16));
+        Af[rr][j] = tr_frag(ad, ad + 4 * 8);
+      });
+    });
+  };
+  auto multiply = [&]() __attribute__((always_inline)) {
+    static_for<0, 2>([&](auto RR) {
+      constexpr int rr = decltype(RR)::value;
+      static_for<0, 5>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto S) {
+          constexpr int s = decltype(S)::value;
+          acc[j][s] = FU_MFMA16W(Af[rr][j], Bf[rr][s], acc[j][s]);
+        });
+      });
+    });
+  };
+  auto wg_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto body = [&](auto Par, int n) __attribute__((always_inline)) {
+    constexpr int par = decltype(Par)::value;
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));    // vmcnt(0): this lane's share of stage n (the builtin, so that hipcc knows the DMA has landed)
+    store_x(par);
+    wg_barrier();                                            // stage n complete; everybody is done with stage n - 1
+    read_frags(Par);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(pt0 + min(n + 1, T - 1), 1 - par);                 // (past the last tile: the last tile again, never read)
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+  };
+  issue(pt0, 0);
+  for (int n = 0; n < T; n += 2) {
+    body(std::integral_constant<int, 0>{}, n);
+    if (n + 1 >= T) break;
+    body(std::integral_constant<int, 1>{}, n + 1);
+  }
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));      // the trailing DMA writes LDS: it must have landed before the reuse
+  wg_barrier();
+
+  // waves 1-3 park their partial sums, wave 0 adds them in wave order and writes the workgroup's slab
+  float* red = reinterpret_cast<float*>(smem_raw);
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        *reinterpret_cast<f32x4w*>(red + (((wave - 1) * 20 + j * 4 + s) * 64 + lane) * 4) = acc[j][s];
+  }
+  wg_barrier();
+  if (wave == 0) {
+    // D tile: lane = column (output channel 16 s + lane % 16), registers = rows 4 g + i = tap 2j + (g >> 1), channels
+    // 4 (g & 1) + i  ->  slab[split][tap][c_in / 4][c_out][4]: one 16-byte store per accumulator tile
+    const int co = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tap = 2 * j + (g >> 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4w v = acc[j][s];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4w*>(red + ((w * 20 + j * 4 + s) * 64 + lane) * 4);
+        if (tap < 9)
+          *reinterpret_cast<f32x4w*>(P.slab + ((((int64_t)split * 9 + tap) * 2 + (g & 1)) * 64 + 16 * s + co) * 4) = v;
+      }
+    }
+  }
+}
+
+static bool wgrad_c8_eligible(const BWgP& P) {
+  const int64_t npx = (int64_t)P.B * P.H * P.W;
+  return P.C0 == 8 && P.C1 == 0 && P.a0 == nullptr && P.Cout == 64 && P.H % WC8::TH == 0 && P.W % WC8::TW == 0 &&
+         npx * 128 < (int64_t(1) << 40) && npx < (int64_t(1) << 31);
+}
+
+static int launch_wgrad_c8(BWgP& P, int target_wgs, const LaunchOpts& o, hipStream_t s) {
+  using C = WC8;
+  P.tilesX = P.W / C::TW; P.tilesY = P.H / C::TH;
+  P.nPix = P.B * P.tilesX * P.tilesY;
+  P.nCi = 1; P.nCo = 1;
+  int S = target_wgs < P.nPix ? target_wgs : P.nPix;
+  if (S < 1) S = 1;
+  P.perSplit = ceil_div(P.nPix, S);
+  P.S = ceil_div(P.nPix, P.perSplit);     // every split owns at least one tile
+  P.rcp_tilesX = host_rcp(P.tilesX); P.rcp_tilesY = host_rcp(P.tilesY);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FU_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf16_c8),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES));
+    attr_set = true;
+  }
+  const ProfSlot ps = o.prof;
+  if (ps.start) (void)hipEventRecord(ps.start, s);
+  hipLaunchKernelGGL(k_wgrad_bf16_c8, dim3(P.S), dim3(C::NT), C::SMEM_BYTES, s, P);
+  if (ps.stop) (void)hipEventRecord(ps.stop, s);
+  FU_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_wgrad_reduce(const float* slab, int S, int Cin, int Cout, int cin_real, float* dw, const float* dbp,
                         int ndb, float* db, hipStream_t s, bool ci4);
 
@@ -1239,6 +1482,7 @@ int launch_conv3x3_wgrad_bf16(const ConvIn& in, const bf16_t* dy, int Cout, floa
   else if (wgrad_mode_env() == 1) st = launch_wgrad_cfg<2, 8>(P, 512, in.opt, s);
   else if (wgrad_mode_env() == 2) st = launch_wgrad_cfg<2, 8>(P, 256, in.opt, s);
 #endif
+  else if (!g_wgrad_force_lockstep && wgrad_c8_eligible(P)) st = launch_wgrad_c8(P, wgrad_c64_target(), in.opt, s);   // the 8-band first conv: K = 72 stream over dy
   else if (P.Cin > 64 && g_wgrad_force_lockstep != 1) st = launch_wgrad_pp(P, wgrad_pp_target(), in.opt, s);   // 512 threads, 128 c_in x 64 c_out, one WG per CU
   else if (P.Cin > 64) st = launch_wgrad_cfg<4, 8>(P, wgrad_pp_target(), in.opt, s);   // (same split as the ping-pong kernel: bit-identical sums)
   else st = launch_wgrad_cfg<2, 8>(P, wgrad_c64_target(), in.opt, s);   // 256 threads, 64 x 64, two WGs per CU

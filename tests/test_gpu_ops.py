@@ -322,6 +322,36 @@ def test_bf16_wgrad_pingpong_kernel_is_bit_identical_to_lockstep(shape, lowp):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 0, 64, 8, 32, False), (2, 8, 0, 64, 16, 64, False), (3, 8, 0, 64, 40, 96, False),
+                                   (5, 8, 0, 64, 64, 32, False), (16, 8, 0, 64, 256, 256, False)])
+def test_bf16_wgrad_first_conv_kernel(shape, lowp):
+    """k_wgrad_bf16_c8 (8 un-normalised input channels -> 64: the K = 72 stream over dy) against torch on the rounded operands
+    and against the general weight-gradient kernel on the same operands: one all-border tile, border + interior tiles, a
+    split that leaves some workgroups one tile short, and the bench shape (512 workgroups x 8 tiles)."""
+    B, C0, C1, Cout, H, W, bn = shape
+    lib = _lib.load()
+    x0, x1, a, b, w, bias, _ = make_conv_case(*shape, seed=7)
+    g = torch.Generator().manual_seed(8)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    d0, ddy = nhwc_bf(x0), nhwc_bf(dy)
+    outs = []
+    for lock in (0, 1):
+        lib.fu_test_force_lockstep_wgrad(lock)
+        dw = torch.full(w.shape, float("nan"), device=DEV)
+        try:
+            check(lib.fu_op_conv3x3_wgrad(_cur["code"], ptr(d0), C0, None, None, None, 0, ptr(ddy), Cout, ptr(dw), B, H, W,
+                                          stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.fu_test_force_lockstep_wgrad(0)
+        outs.append(dw.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0], outs[1]) < 2e-6          # same exact products, another fp32 summation order
+    if B * H * W <= 1 << 16:
+        ref = torch.nn.grad.conv2d_weight(bf(x0), w.shape, bf(dy), padding=1)
+        assert rel_err(outs[0], ref) < 1e-4
+
+
 @pytest.mark.parametrize("shape", BF_SHAPES)
 def test_conv3x3_bf16_wgrad(shape, wgrad_path, lowp):
     B, C0, C1, Cout, H, W, bn = shape

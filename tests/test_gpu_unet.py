@@ -331,7 +331,14 @@ def test_full_size_properties(prec):
             _lib.check(lib.fu_set_side_stream(net._ctx, 0))
             l4 = net.train_step(x, t, 0).item()
             torch.cuda.synchronize()
-            assert l4 == l1 and torch.equal(net.flat_grads(), g1)
+            assert l4 == l1
+            # (one exception since round 4: the 8-band first conv's weight gradient has its own kernel, k_wgrad_bf16_c8, which
+            #  the lock-step switch turns off -- the same exact products in another fp32 summation order)
+            for (k, p), gv1, gv4 in zip(net.named_parameters(), _views(net, g1), _views(net, net.flat_grads())):
+                if k == "inc.double_conv.0.weight":
+                    assert rel(gv4, gv1) <= 1e-5, (k, rel(gv4, gv1))
+                else:
+                    assert torch.equal(gv4, gv1), k
         finally:
             lib.fu_test_force_lockstep_wgrad(0)
             _lib.check(lib.fu_set_side_stream(net._ctx, 1))
