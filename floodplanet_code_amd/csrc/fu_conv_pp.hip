@@ -58,7 +58,8 @@ struct PCfg {
   static constexpr int G1_ROW_UNITS = 16 * HWd * 4, G1_UNITS = G1_ROW_UNITS + 16;
   static constexpr int AB_OFF = 2 * STAGE, AB_FLOATS = 1024;                 // BN scale / shift of source 0
   static constexpr int RED_OFF = AB_OFF + AB_FLOATS * 4, RED_FLOATS = 2 * 8 * 32 * 2;   // [tile parity][wave][32 ch][2]
-  static constexpr int SMEM_BYTES = RED_OFF + RED_FLOATS * 4;                // 160256 <= 163840
+  static constexpr int BIAS_OFF = RED_OFF + RED_FLOATS * 4, BIAS_FLOATS = 512;   // forward launches: the conv bias (N <= 512)
+  static constexpr int SMEM_BYTES = BIAS_OFF + BIAS_FLOATS * 4;              // 162304 <= 163840
   static constexpr int M_STEPS = 3 * (8 + 2);                                // (column shift, input row) steps per chunk
 };
 
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sAB = reinterpret_cast<float*>(smem_raw + Cfg::AB_OFF);     // [2][512]
   float* sRed = reinterpret_cast<float*>(smem_raw + Cfg::RED_OFF);
+  float* sBias = reinterpret_cast<float*>(smem_raw + Cfg::BIAS_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     for (int ro = 0; ro < 8; ++ro) yr[ro] = *reinterpret_cast<const uint4*>(ybase + (size_t)ro * (size_t)(P.W * P.N) * 2);
   };
   auto epilogue = [&]() __attribute__((always_inline)) {
+    FU_STAMP(e0);
     if constexpr (BNB) bnb_request();
     int pixT, n0, x0, y0, bb;
     decode(mv, pixT, n0, x0, y0, bb);
@@ -463,41 +466,49 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     const bool to0 = n0 < P.D0;                                      // uniform: D0 % 64 == 0 with two destinations
     char* dbase = reinterpret_cast<char*>(to0 ? P.dst0 + nl : P.dst1 + (nl - P.D0));
     const int dstride = to0 ? P.D0 : P.D1;
-    float biasv[8];
+    // The epilogue has a phase to itself (see body): no MFMA runs beside it, so (i) the sums, the sums of squares and the bias
+    // add are PACKED fp32 operations (v_pk_add_f32 / v_pk_fma_f32: the same IEEE operations per component -- slow only beside
+    // a co-resident MFMA stream), and (ii) the accumulators are cleared by the idle matrix pipe itself: 0 x 0 + 0 through one
+    // MFMA per accumulator tile (16 issues) instead of 64 v_mov_b32.
+    f32x2 bias2[4], s2[4], q2[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) biasv[c] = 0.f;
+    for (int c = 0; c < 4; ++c) { bias2[c] = f32x2{0.f, 0.f}; s2[c] = f32x2{0.f, 0.f}; q2[c] = f32x2{0.f, 0.f}; }
     if constexpr (FWD) {
-      if (P.bias != nullptr) {
-        const float4 b0 = *reinterpret_cast<const float4*>(P.bias + nl), b1 = *reinterpret_cast<const float4*>(P.bias + nl + 4);
-        biasv[0] = b0.x; biasv[1] = b0.y; biasv[2] = b0.z; biasv[3] = b0.w;
-        biasv[4] = b1.x; biasv[5] = b1.y; biasv[6] = b1.z; biasv[7] = b1.w;
-      }
+      const float4 b0 = *reinterpret_cast<const float4*>(sBias + nl), b1 = *reinterpret_cast<const float4*>(sBias + nl + 4);
+      bias2[0] = f32x2{b0.x, b0.y}; bias2[1] = f32x2{b0.z, b0.w}; bias2[2] = f32x2{b1.x, b1.y}; bias2[3] = f32x2{b1.z, b1.w};
     }
-    float st[16];                                                    // [0, 8): sums, [8, 16): sums of squares
-#pragma unroll
-    for (int c = 0; c < 16; ++c) st[c] = 0.f;
+    typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
+    u32x4z zbits = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(zbits));                                  // (opaque: the clearing MFMAs are not folded into moves)
+    const frag8_t zf = __builtin_bit_cast(frag8_t, zbits);
+    auto clear = [&](f32x4& a) __attribute__((always_inline)) { a = FU_MFMA16(zf, zf, (f32x4{0.f, 0.f, 0.f, 0.f})); };
+    const size_t rowb = (size_t)P.W * (size_t)dstride * 2;           // one address product per tile, one 64-bit add per row
+    char* dp = dbase + (size_t)((bb * P.H + y0 + rg * 8) * P.W + x0 + lx) * (size_t)dstride * 2;
 #pragma unroll
     for (int ro = 0; ro < 8; ++ro) {
-      const int oy = y0 + rg * 8 + ro, ox = x0 + lx;
       unsigned o[4];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float v0 = acc[ro][q][0], v1 = acc[ro][q][1], v2 = acc[ro][q][2], v3 = acc[ro][q][3];
+        const f32x2 lo = {acc[ro][q][0], acc[ro][q][1]}, hi = {acc[ro][q][2], acc[ro][q][3]};
         if constexpr (FWD) {
-          st[4 * q + 0] += v0; st[4 * q + 1] += v1; st[4 * q + 2] += v2; st[4 * q + 3] += v3;
-          st[8 + 4 * q + 0] = fmaf(v0, v0, st[8 + 4 * q + 0]); st[8 + 4 * q + 1] = fmaf(v1, v1, st[8 + 4 * q + 1]);
-          st[8 + 4 * q + 2] = fmaf(v2, v2, st[8 + 4 * q + 2]); st[8 + 4 * q + 3] = fmaf(v3, v3, st[8 + 4 * q + 3]);
-          o[2 * q + 0] = pack_e2(f32x2{v0 + biasv[4 * q + 0], v1 + biasv[4 * q + 1]});
-          o[2 * q + 1] = pack_e2(f32x2{v2 + biasv[4 * q + 2], v3 + biasv[4 * q + 3]});
+          s2[2 * q + 0] += lo; s2[2 * q + 1] += hi;
+          q2[2 * q + 0] = __builtin_elementwise_fma(lo, lo, q2[2 * q + 0]);
+          q2[2 * q + 1] = __builtin_elementwise_fma(hi, hi, q2[2 * q + 1]);
+          o[2 * q + 0] = pack_e2(lo + bias2[2 * q + 0]);
+          o[2 * q + 1] = pack_e2(hi + bias2[2 * q + 1]);
         } else {
-          o[2 * q + 0] = pack_e2(f32x2{v0, v1});
-          o[2 * q + 1] = pack_e2(f32x2{v2, v3});
+          o[2 * q + 0] = pack_e2(lo);
+          o[2 * q + 1] = pack_e2(hi);
         }
-        if constexpr (!BNB) acc[ro][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!BNB) clear(acc[ro][q]);
       }
-      char* dp = dbase + (size_t)((bb * P.H + oy) * P.W + ox) * (size_t)dstride * 2;
       *reinterpret_cast<uint4*>(dp) = make_uint4(o[0], o[1], o[2], o[3]);
+      dp += rowb;
     }
+    FU_STAMP(e1);
+    float st[16];                                                    // [0, 8): sums, [8, 16): sums of squares
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { st[2 * c] = s2[c].x; st[2 * c + 1] = s2[c].y; st[8 + 2 * c] = q2[c].x; st[8 + 2 * c + 1] = q2[c].y; }
     if constexpr (FWD) {
       if (P.stats) {
         row_sums(st);
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
             tt[k] += gm;
             tt[4 + k] = fmaf(gm, yv[k], tt[4 + k]);
           }
-          acc[ro][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          clear(acc[ro][q]);
         }
         row_sums(tt);
         if (lx == 15) {
@@ -537,6 +548,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
         }
       });
     }
+#ifdef FU_CONV_STAMPS
+    { const unsigned long long e2 = __builtin_amdgcn_s_memtime(); tSd += e1 - e0; tSl += e2 - e1; }
+#endif
     pend = true; pend_pixT = pixT; pend_n0 = n0; pend_par = tpar;
     tpar ^= 1;
     mv += grid;
@@ -583,6 +597,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   if constexpr (BN) {
     for (int c = tid; c < P.C0; c += Cfg::NT) { sAB[c] = P.a0[c]; sAB[512 + c] = P.b0[c]; }
   }
+  if constexpr (FWD) {       // the bias from LDS: a global load at the head of the epilogue was an exposed L2 latency per tile
+    for (int c = tid; c < P.N; c += Cfg::NT) sBias[c] = P.bias != nullptr ? P.bias[c] : 0.f;
+  }
   // (measured, no effect on any layer: s_setprio 1 for the younger half once at kernel start -- MI355X_MICROARCH.md "Two waves per
   //  SIMD" item 4 --, and s_setprio 1 / 2 around the MFMA phase)
   load_tile(lv);
@@ -605,8 +622,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   }
 
   // One step of a group: { MFMA phase + conversion of the next step ; barrier ; weight DMA, refill of the converted set,
-  // [sums of the previous tile], [epilogue], first fragments of the next MFMA phase ; barrier }.  Group 1 runs one phase
-  // behind group 0, so on every SIMD one wave multiplies while the other moves data.
+  // [sums of the previous tile], first fragments of the next MFMA phase ; barrier }.  Group 1 runs one phase behind group 0,
+  // so on every SIMD one wave multiplies while the other moves data.
+  // The epilogue of a tile gets a phase of its own, the same one for both groups: { ... ; barrier ; data movement ; barrier ;
+  // EPILOGUE ; barrier } in group 0, { ... ; barrier ; EPILOGUE ; barrier ; data movement ; barrier } in group 1 (one phase
+  // behind).  Its 450 (forward, with statistics) to 900 (BatchNorm-backward sums) vector instructions ran beside the other
+  // group's MFMA phase at ~10 cycles each and stretched TWO phases per tile from ~2700 to 5000-7500 cycles (group 0's epilogue
+  // beside group 1's last MFMA phase, group 1's beside group 0's first of the next tile); with both groups' epilogues in one
+  // phase without MFMAs they issue at the VALU's own rate and the matrix pipe idles once per tile instead of waiting twice.
+#ifndef FU_PP_JOINT_EPILOGUE
+#define FU_PP_JOINT_EPILOGUE 1      // (0: the epilogue inside the data-movement phase, A/B builds)
+#endif
   auto body = [&](auto Par) __attribute__((always_inline)) {
     constexpr int par = decltype(Par)::value;
     FU_STAMP(s0);
@@ -622,16 +648,58 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
     FU_STAMP(s2);
     const bool tile_end = mk + 1 == nChunks && mstep < T;            // uniform (an odd step count ends with a dummy step)
     ++mstep;
-    // group 0: the weights of step s+1 (stage 1 - par: group 1 left it one phase ago); group 1: of step s+2 (stage par: group
-    // 0 multiplied it one phase ago, and group 1's own half of that stage is not touched)
-    dma_weights(grp ? par : 1 - par);
-    FU_STAMP(s2a);
-    load_all(std::integral_constant<int, 1 - par>{});                // refill the set this phase's conversion has emptied
-    FU_STAMP(s2b);
-    vm_wait5();                                                      // the DMA pieces have landed (the five loads stay in flight)
+    auto move_data = [&]() __attribute__((always_inline)) {
+      // group 0: the weights of step s+1 (stage 1 - par: group 1 left it one phase ago); group 1: of step s+2 (stage par: group
+      // 0 multiplied it one phase ago, and group 1's own half of that stage is not touched)
+      dma_weights(grp ? par : 1 - par);
+      load_all(std::integral_constant<int, 1 - par>{});              // refill the set this phase's conversion has emptied
+      vm_wait5();                                                    // the DMA pieces have landed (the five loads stay in flight)
+      if (wave == 0 && pend) combine();
+    };
+#if FU_PP_JOINT_EPILOGUE
+    if (tile_end && grp) {                                           // (uniform per wave)
+      epilogue(); mk = 0;
+      FU_STAMP(s3);
+      wg_barrier();
+      FU_STAMP(s3a);
+      move_data();
+      FU_STAMP(s3b);
+      mfma_prefetch(std::integral_constant<int, 1 - par>{});
+      FU_STAMP(s4);
+      wg_barrier();
+#ifdef FU_CONV_STAMPS
+      const unsigned long long s5 = __builtin_amdgcn_s_memtime();
+      tM += s1 - s0; tB1 += s2 - s1; tSw += s3 - s2; tS += s3b - s3a; tE += s4 - s3b; tB2 += s5 - s4; tSv += s3a - s3; tSc += 1;
+#endif
+    } else if (tile_end) {
+      move_data();
+      FU_STAMP(s3);
+      wg_barrier();
+      FU_STAMP(s3a);
+      epilogue(); mk = 0;
+      FU_STAMP(s3b);
+      mfma_prefetch(std::integral_constant<int, 1 - par>{});
+      FU_STAMP(s4);
+      wg_barrier();
+#ifdef FU_CONV_STAMPS
+      const unsigned long long s5 = __builtin_amdgcn_s_memtime();
+      tM += s1 - s0; tB1 += s2 - s1; tS += s3 - s2; tSw += s3b - s3a; tE += s4 - s3b; tB2 += s5 - s4; tSv += s3a - s3; tSc += 1;
+#endif
+    } else {
+      move_data();
+      ++mk;
+      FU_STAMP(s3);
+      mfma_prefetch(std::integral_constant<int, 1 - par>{});         // first fragments of the next MFMA phase (complete: header)
+      FU_STAMP(s4);
+      wg_barrier();
+#ifdef FU_CONV_STAMPS
+      const unsigned long long s5 = __builtin_amdgcn_s_memtime();
+      tM += s1 - s0; tB1 += s2 - s1; tS += s3 - s2; tE += s4 - s3; tB2 += s5 - s4;
+#endif
+    }
+#else
+    move_data();
     FU_STAMP(s3);
-    if (wave == 0 && pend) combine();
-    FU_STAMP(s3a);
     if (tile_end) { epilogue(); mk = 0; } else { ++mk; }
     FU_STAMP(s3b);
     mfma_prefetch(std::integral_constant<int, 1 - par>{});           // first fragments of the next MFMA phase (complete: header)
@@ -640,7 +708,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 #ifdef FU_CONV_STAMPS
     const unsigned long long s5 = __builtin_amdgcn_s_memtime();
     tM += s1 - s0; tB1 += s2 - s1; tS += s3 - s2; tE += s4 - s3; tB2 += s5 - s4;
-    tSd += s2a - s2; tSl += s2b - s2a; tSv += s3 - s2b; tSw += s3b - s3a; tSc += tile_end ? 1 : 0;
+    tSw += s3b - s3; tSc += tile_end ? 1 : 0;
+#endif
 #endif
   };
 #ifdef FU_CONV_STAMPS
@@ -670,6 +739,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
 bool conv3x3_pp_eligible(const BConvP& P) {
   if (!conv3x3_rs_eligible(P)) return false;
   if ((P.H % 32) != 0) return false;
+  if ((P.bias != nullptr || P.stats != nullptr) && P.N > PCfg::BIAS_FLOATS) return false;   // (the LDS bias table of the forward launches)
   const int64_t tiles = (int64_t)P.B * (P.H / 32) * (P.W / 16) * (P.N / 64);
   return tiles >= 8 && tiles < ((int64_t)1 << 24);
 }

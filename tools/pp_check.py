@@ -19,7 +19,7 @@ FWD = [(2, 64, 0, 64, 64, 48, True), (2, 32, 32, 128, 32, 32, True), (16, 64, 0,
 DGR = [(2, 64, 64, 0, 64, 32), (16, 64, 64, 0, 256, 256), (16, 64, 64, 64, 256, 256), (16, 512, 512, 512, 32, 32),
        (16, 128, 128, 0, 128, 128), (16, 256, 128, 128, 128, 128)]
 # B, Cout, C0, H, W
-BNS = [(4, 64, 64, 256, 256), (8, 128, 128, 128, 128), (2, 256, 192, 32, 32), (16, 64, 64, 256, 256), (1, 64, 64, 64, 32)]
+BNS = [(4, 64, 64, 256, 256), (8, 128, 128, 128, 128), (2, 256, 192, 32, 32), (16, 64, 64, 256, 256), (2, 64, 64, 64, 64)]
 s = lambda: torch.cuda.current_stream().cuda_stream
 bad = 0
 

@@ -28,8 +28,9 @@ def run(B, C0, Cout, H, W, bn=True):
     for g in (0, 1):
         x = d[:, 4 * g:4 * g + 4, :]
         t = x[:, :, 8]
-        print(f"  group {g}: per step: mfma+convert {med(x[:,:,0]/t):.0f} | barrier {med(x[:,:,1]/t):.0f} | DMA+refill+wait {med(x[:,:,2]/t):.0f} | combine+epilogue+prefetch {med(x[:,:,3]/t):.0f} | barrier {med(x[:,:,4]/t):.0f} || loop {med(x[:,:,5]/t):.0f} per step, prologue+tail {med(x[:,:,6]-x[:,:,5]):.0f} | lifetime {med(x[:,:,6]):.0f} cycles = {med(x[:,:,7])/100:.1f} us -> {med(x[:,:,6])/med(x[:,:,7])*100:.0f} MHz")
-        print(f"           DMA issue {med(x[:,:,10]/t):.0f} + load issue {med(x[:,:,14]/t):.0f} + wait for the DMA {med(x[:,:,13]/t):.0f} | epilogue {med(x[:,:,11]/np.maximum(x[:,:,12],1)):.0f} cycles each ({med(x[:,:,12]):.0f} per workgroup) | prologue {med(x[:,:,15]):.0f}, tail {med(x[:,:,6]-x[:,:,5]-x[:,:,15]):.0f}")
+        print(f"  group {g}: per step: mfma+convert {med(x[:,:,0]/t):.0f} | barrier {med(x[:,:,1]/t):.0f} | DMA+refill+wait+combine {med(x[:,:,2]/t):.0f} | prefetch {med(x[:,:,3]/t):.0f} | barrier {med(x[:,:,4]/t):.0f} || loop {med(x[:,:,5]/t):.0f} per step, prologue+tail {med(x[:,:,6]-x[:,:,5]):.0f} | lifetime {med(x[:,:,6]):.0f} cycles = {med(x[:,:,7])/100:.1f} us -> {med(x[:,:,6])/med(x[:,:,7])*100:.0f} MHz")
+        ne = np.maximum(x[:,:,12],1)
+        print(f"           per tile: epilogue {med(x[:,:,11]/ne):.0f} cycles (rows: convert + store {med(x[:,:,10]/ne):.0f}, sums {med(x[:,:,14]/ne):.0f}), barrier between the two tile-end phases {med(x[:,:,13]/ne):.0f} ({med(x[:,:,12]):.0f} tiles per workgroup) | prologue {med(x[:,:,15]):.0f}, tail {med(x[:,:,6]-x[:,:,5]-x[:,:,15]):.0f}")
     st = d[:, :, 9]; end = st + d[:, :, 6]
     print(f"  span {end.max() - st.min():.0f} cycles; start skew p95 {np.percentile(st - st.min(), 95):.0f}")
 for a in [(16, 64, 64, 256, 256), (16, 128, 128, 128, 128), (16, 256, 256, 64, 64), (16, 512, 512, 32, 32), (16, 64, 64, 256, 256, False)]:
