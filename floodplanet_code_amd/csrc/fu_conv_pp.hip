@@ -755,9 +755,14 @@ bool conv3x3_pp_preferred(const BConvP& P) {
 // vector instructions per wave and tile in the epilogue, which runs beside the other group's MFMA phase at ~8 cycles per
 // instruction; on the two-chunk 256 x 256 layers that is the kernel's critical path (64 -> 64: 125 us against 114 on the
 // two-workgroup kernel, whose second workgroup covers it); from 256 input channels on it disappears (512 -> 512 at 32 x 32: 63
-// against 74 us).
+// against 74 us).  With the epilogue in a phase of its own (body) the picture is the same -- one-stream trace, pp | rs<8>: 64 -> 64
+// at 256 x 256 125 / 117 | 115 / 114 us, 128 -> 64 at 128 x 128 65 | 54, 256 -> 128 at 64 x 64 49 | 44, 128 -> 128 at 128 x 128 92 | 83
+// (-DFU_PP_BNB_MIN_CIN=64 builds).
+#ifndef FU_PP_BNB_MIN_CIN
+#define FU_PP_BNB_MIN_CIN 256
+#endif
 bool conv3x3_pp_preferred_bnb(const BConvP& P) {
-  return conv3x3_pp_preferred(P) && P.Cin >= 256;
+  return conv3x3_pp_preferred(P) && P.Cin >= FU_PP_BNB_MIN_CIN;
 }
 
 int launch_conv3x3_pp(BConvP& P, const LaunchOpts& o, hipStream_t s) {
