@@ -1432,13 +1432,20 @@ static int wgrad_mode_env() {
 // 128: 5.67 (another box, against 5.78 at 256).  Below 208 the step gains another 0.5 % while the dgrad launches -- which then
 // share the GPU with the longer-running weight-gradient launch of the layer before -- lose 5 %: 208 takes most of the one
 // without the other.  (FU_WGRAD_TARGET overrides it in -DFU_EXPERIMENTS builds.)
+// Round 4: 160.  The persistent conv kernel (fu_conv_pp.hip) takes a whole CU per workgroup like this one, so a dgrad launch that
+// starts beside a weight-gradient launch runs on the CUs this kernel leaves and the rest of its grid waits; measured again with
+// that dispatch, two boxes, ms per step | conv class TFLOP/s event-timed in the step: 256: 5.60 | 913, 208: 5.40-5.47 | 890-922,
+// 192: 5.34-5.39 | 853-866, 176: 5.33-5.40 | 848-867, 160: 5.28-5.35 | 834-843, 144: 5.38 | 825, 128: 5.57 | 825 -- the step is the
+// product's metric (-1.8 % at 160); the conv launches' event-timed rate falls with it by construction (they share more of their
+// own duration), their rate with the GPU to themselves (roofline.achieved_serial) does not change.  Capping the dgrad launches'
+// grid to the complement instead (FU_PP_GRID: 128 + 128, 112 + 144, 96 + 160) is no better (5.35-5.40) and slower alone.
 static int wgrad_pp_target() {
 #ifdef FU_EXPERIMENTS
   static int t = -1;
-  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 208; }
+  if (t < 0) { const char* e = getenv("FU_WGRAD_TARGET"); t = e ? atoi(e) : 160; }
   return t;
 #else
-  return 208;
+  return 160;
 #endif
 }
 
