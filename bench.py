@@ -497,16 +497,31 @@ def main():
 
     if world > 1:   # communicator set-up + parameter broadcast outside the steps (also with --warmup 0)
         trainer._sync_initial_state(dev)
-    for _ in range(args.warmup):
+    lib = _lib.load()
+    stride = int(os.environ.get("FU_BENCH_EVENT_STRIDE", "8"))
+    for w in range(args.warmup):
+        # the LAST warm-up step runs with the launch events on: the first event-timed step creates ~100 events and pays their first
+        # records -- 2.2 ms on a 5.3 ms step (FU_BENCH_DUMP_STEPS=1: 7.57 / 5.39 / 5.37 ...), a one-time cost that belongs to the
+        # warm-up, not to the K timed steps (it was 3 % of `value` at K = 20 through round 3)
+        warm_events = stride > 0 and w == args.warmup - 1 and net._ctx is not None
+        if warm_events:
+            _lib.check(lib.fu_profile_enable(net._ctx, 1))
+            trainer._graph_off = True
         trainer.step(x, target, 0)
+        if warm_events:
+            _lib.check(lib.fu_profile_enable(net._ctx, 0))
+            trainer._graph_off = False
     if net._ctx is None:      # --warmup 0: the context is created by the first forward; the event profiler needs one
         trainer.step(x, target, 0)
-    lib = _lib.load()
     # HIP events around every conv / wgrad launch serialise the kernel boundaries (~2 us per pair: 6.39 -> 6.66 ms per
     # step when every step is timed, same box), so the live roofline measurement samples every EVENT_STRIDE-th step of
     # the timed region; FU_BENCH_EVENT_STRIDE=1 times them all, 0 none
-    stride = int(os.environ.get("FU_BENCH_EVENT_STRIDE", "8"))
     sampled = 0
+    # event-timed steps: every stride-th, starting mid-stride (not the first step behind the synchronisation: its launches meet an
+    # empty queue); a run shorter than that samples its last step
+    sample_steps = set(i for i in range(args.steps) if stride > 0 and i % stride == stride // 2)
+    if stride > 0 and not sample_steps and args.steps > 0:
+        sample_steps = {args.steps - 1}
     if world > 1 and getattr(trainer, "_reducer", None) is not None:
         trainer._reducer.reset_timing()     # the exposed all-reduce waits of the TIMED steps only
     # one event per step boundary on the compute stream (a record is ~1 us of host time and serialises nothing): the
@@ -516,7 +531,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        on = stride > 0 and i % stride == 0
+        on = i in sample_steps
         if on:
             _lib.check(lib.fu_profile_enable(net._ctx, 1 if sampled == 0 else 2))
             sampled += 1
@@ -528,7 +543,10 @@ def main():
         marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get("FU_BENCH_DUMP_STEPS"):      # diagnostics: the per-step durations in launch order
+        print("step_ms " + " ".join(f"{v:.3f}" for v in step_ms), file=sys.stderr)
+    step_ms = sorted(step_ms)
     step_ms_median = (step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
                       0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])) if step_ms else None
     if world > 1:
