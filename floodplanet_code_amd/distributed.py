@@ -196,18 +196,21 @@ class DataParallelTrainer:
         self._gscal_ev = [None] * 8
         lib = _lib.load()
         torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
         dot = os.environ.get("FU_GRAPH_DOT")                          # diagnostics: hipGraphDebugDotPrint of the captured step (tools/graph_dot.py)
-        if dot:
-            g.enable_debug_mode()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             net._forward_raw(self._gx, True, want_logits=False)
             self._gloss = net._loss_raw(self._gt, self._g_ignore, dev)
             net._backward_raw(None, dev)
             _lib.check(lib.fu_adam_step_dev(net._ctx, self._gscal.data_ptr(), net._stream(dev)))
         net._generation -= 1          # (the capture enqueued nothing; the bookkeeping of _forward_raw is redone per replay)
-        if dot:
-            g.debug_dump(dot)
+        if dot:       # (torch's own debug_dump writes nothing on this ROCm build)
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+            rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(g.raw_cuda_graph()), dot.encode(), 0)
+            if rc != 0:
+                raise RuntimeError(f"hipGraphDebugDotPrint -> {rc}")
         self._graph = g
 
     def _graph_step(self, x, target, ignore_index):
