@@ -53,21 +53,41 @@ class SegmentationMetrics:
         `_jaccard_index_reduce(confmat, average="micro", ignore_index)` -- num = sum(diag), denom = sum(union) minus
         union[ignore_index] when 0 <= ignore_index < num_classes, union = rows + cols - diag -- and its stat-scores
         micro F1 / Accuracy (tp = #correct, fp = fn = N - tp)."""
-        m = m.double()
-        tp = m.diag().sum()
-        tot = m.sum()
-        fp = fn = tot - tp
-        one = torch.ones((), dtype=torch.float64, device=m.device)
-        f1 = torch.where(tot > 0, 2 * tp / torch.where(tot > 0, 2 * tp + fp + fn, one), 0 * one)
-        acc = torch.where(tot > 0, tp / torch.where(tot > 0, tot, one), 0 * one)
-        union = m.sum(0) + m.sum(1) - m.diag()
-        denom = union.sum()
-        if self.ignore_index is not None and 0 <= self.ignore_index < self.num_classes:
-            denom = denom - union[self.ignore_index]
-        jac = torch.where(denom > 0, tp / torch.where(denom > 0, denom, one), 0 * one)
+        # Seven tensor ops instead of ~35 (round 4: the plugin's training_step was host-bound on these tiny launches): every
+        # quantity is an exact integer in fp64, so the linear parts are two products with constant 0 / 1 / 2 matrices --
+        #   s = [tp, tot, union[ii]] = W1 . vec(M);   [num | den] = W2 . s  with
+        #   num = (2 tp, tp, tp),  den = (2 tp + fp + fn, tot, sum(union) - union[ii]),  fp = fn = tot - tp,  sum(union) = 2 tot - tp
+        # -- and the quotients are the same IEEE divisions as before (bit-identical results, tests/test_models_api.py).
+        w1, w2 = self._reduce_matrices(m.device)
+        s = (w1 * m.reshape(1, -1).double()).sum(1)
+        nd = (w2 * s.reshape(1, -1)).sum(1)
+        num, den = nd[:3], nd[3:]
+        ok = den > 0
+        res = torch.where(ok, num / torch.where(ok, den, torch.ones_like(den)), torch.zeros_like(den)).float()
         p = self.prefix
-        return {f"{p}MulticlassF1Score": f1.float(), f"{p}MulticlassJaccardIndex": jac.float(),
-                f"{p}MulticlassAccuracy": acc.float()}
+        return {f"{p}MulticlassF1Score": res[0], f"{p}MulticlassJaccardIndex": res[2], f"{p}MulticlassAccuracy": res[1]}
+
+    def _reduce_matrices(self, device):
+        cache = getattr(self, "_rm", None)
+        if cache is not None and cache[0] == device:
+            return cache[1], cache[2]
+        n = self.num_classes
+        ii = self.ignore_index if (self.ignore_index is not None and 0 <= self.ignore_index < n) else None
+        w1 = torch.zeros(3, n, n, dtype=torch.float64)
+        w1[0] = torch.eye(n, dtype=torch.float64)                    # tp = trace
+        w1[1] = 1.0                                                  # tot
+        if ii is not None:                                           # union[ii] = row ii + column ii - M[ii, ii]
+            w1[2, ii, :] += 1.0
+            w1[2, :, ii] += 1.0
+            w1[2, ii, ii] -= 1.0
+        # rows: num_f1, num_acc, num_jac, den_f1, den_acc, den_jac over s = (tp, tot, union[ii])
+        w2 = torch.tensor([[2.0, 0.0, 0.0], [1.0, 0.0, 0.0], [1.0, 0.0, 0.0],
+                           [0.0, 2.0, 0.0],                          # 2 tp + 2 (tot - tp)
+                           [0.0, 1.0, 0.0],
+                           [-1.0, 2.0, -1.0]], dtype=torch.float64)   # (2 tot - tp) - union[ii]
+        w1, w2 = w1.reshape(3, n * n).to(device), w2.to(device)
+        self._rm = (device, w1, w2)
+        return w1, w2
 
     # -- torchmetrics-like protocol -----------------------------------------------------------------
     def _accumulate(self, c: torch.Tensor) -> None:
