@@ -16,7 +16,8 @@
 //     wave's MFMAs beside the other wave's VALU / LDS-store work all the time (MI355X_MICROARCH.md, "Two waves per SIMD").
 //   * persistent: a workgroup walks its tiles (static round-robin over the XCD-aware tile order) as ONE flat sequence of
 //     (tile, chunk) steps -- the first chunk of the next tile is fetched and staged while the last chunk of this tile is
-//     multiplied, and a group's epilogue (convert, statistics, stores) runs while the other group multiplies.
+//     multiplied.  A tile's epilogue (convert, statistics, stores) ran beside the other group's MFMA phase in the first
+//     builds; it now has a phase of its own, shared by both groups (see body: it is bound by vector-ALU cycles either way).
 //   * every weight fragment a group reads was DMA'd by the OTHER group at least one phase earlier, and the halo rows a wave
 //     needs first (rows with bit 2 clear) are converted by group 0, whose conversion of a step ends one phase before group
 //     0's and two phases before group 1's MFMA phase of that step: the first fragments of an MFMA phase are complete
@@ -88,8 +89,8 @@ constexpr int pp_ops_before(int g) { int n = 0; for (int i = 0; i < g; ++i) n +=
 // plain source takes a = 1, b = 0 and a NaN floor, so that the instruction stream of a step does not depend on its source --
 // a run-time choice between two MFMA phases made hipcc spill 157 registers at the join).
 // FWD: a forward launch -- bias and the per-tile BatchNorm statistics (sum, sum of squares) of the epilogue exist only here; a
-// dgrad launch has neither, and its epilogue is a third of the vector instructions (the epilogue runs beside the other
-// group's MFMA phase and gets the vector issue port only in the gaps that phase leaves: 5000-7500 cycles in the first build).
+// dgrad launch has neither, and its epilogue is a third of the vector instructions (beside the other group's MFMA phase the
+// epilogue got the vector issue port only in the gaps that phase leaves: 5000-7500 cycles in the first build; see body).
 template <bool BNB, bool BN, bool FWD>
 __global__ __launch_bounds__(512) void k_conv3x3_bf16_pp(BConvP P) {
   using Cfg = PCfg;
@@ -752,7 +753,7 @@ bool conv3x3_pp_preferred(const BConvP& P) {
 }
 
 // ... of a dgrad launch that is asked for the BatchNorm-backward sums of its destination: from 8 chunks on.  The sums are ~450
-// vector instructions per wave and tile in the epilogue, which runs beside the other group's MFMA phase at ~8 cycles per
+// vector instructions per wave and tile in the epilogue, which ran beside the other group's MFMA phase at ~8 cycles per
 // instruction; on the two-chunk 256 x 256 layers that is the kernel's critical path (64 -> 64: 125 us against 114 on the
 // two-workgroup kernel, whose second workgroup covers it); from 256 input channels on it disappears (512 -> 512 at 32 x 32: 63
 // against 74 us).  With the epilogue in a phase of its own (body) the picture is the same -- one-stream trace, pp | rs<8>: 64 -> 64
