@@ -410,6 +410,38 @@ def loader_bench(args, dev, host_budget=20.0, device_epochs=4):
         dt = time.perf_counter() - t0
         out[f"tiles_timed_resize_{mode}"] = n
         out[f"tiles_per_s_resize_{mode}"] = round(n / dt, 1)
+        if mode == "device":
+            # which stage caps the device path: ONE collated host batch pushed through the device stage (H2D copies of the
+            # windows + tables, Lanczos, normalisation / padding, augmentation) over and over -- what is left of the loader when
+            # the DataLoader workers cost nothing
+            from floodplanet_code_amd import augment
+            import numpy as np
+            raw = next(iter(ld._dl))
+            rng = np.random.RandomState(0)
+            def device_stage():
+                o = ld._assemble(raw)
+                flags, angles = augment.sample_transforms(o["image"].shape[0], {}, rng)
+                return augment.apply(o["image"], o["target"], flags, angles, target_fill=0)
+            for _ in range(5):
+                device_stage()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            reps = 60
+            for _ in range(reps):
+                device_stage()
+            torch.cuda.synchronize(dev)
+            rate = reps * args.batch / (time.perf_counter() - t1)
+            out["tiles_per_s_device_stage_alone"] = round(rate, 1)
+            # ... and the host pipeline alone: the same DataLoader iterated without the device stage (workers: TIFF decode of
+            # the source windows, cut-outs, 8-tap tables, collation; main process: queue hand-off + pinning)
+            m, t2 = 0, time.perf_counter()
+            for b in ld._dl:
+                m += b["target"].shape[0]
+            host_rate = m / (time.perf_counter() - t2)
+            out["tiles_per_s_host_pipeline_alone"] = round(host_rate, 1)
+            out["capped_by"] = (f"the host pipeline (DataLoader with {args.loader_workers} workers: {host_rate:.0f} tiles/s alone, "
+                                f"{1e3 * args.batch / host_rate:.1f} ms per batch); the device stage alone sustains {rate:.0f} tiles/s"
+                                if rate > 1.15 * host_rate else "the device stage (H2D copies + kernels)")
         del ld
     return out
 
